@@ -1,0 +1,128 @@
+"""Pins the CPU oracle (oracle/dme_oracle.c) against golden vectors produced by the reference
+itself (tests/golden/make_golden.py, DE variant = DirichletEstimation/).  Everything here is
+bit-exact: the oracle keeps the reference's summation order and libm calls.  The NumPy-port
+goldens ("NP") differ from DE only by summation order and are checked to 1e-11."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_append_rows_bit_exact(oracle, name):
+    fx = load_golden(name)
+    st = oracle.append_rows(fx["X"])
+    assert [list(map(int, u)) for u in st.U] == fx["U"]
+    assert list(map(int, st.V)) == fx["V"]
+    # DE/fdp.py:87-89 accumulator and :104-108 normalisation, same order -> same bits
+    assert st.init_acc.tolist() == fx["init_acc"]
+    assert st.cli_init_alphas().tolist() == fx["alpha0_cli"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_closed_form_matches_loops(oracle, name):
+    """U[k][n] = #{i: x_ik > n}, V[n] = #{i: sum_k x_ik > n}."""
+    fx = load_golden(name)
+    X = fx["X"].astype(np.int64)
+    for k in range(fx["K"]):
+        col = X[:, k]
+        m = int(col.max())
+        assert [int((col > n).sum()) for n in range(m)] == fx["U"][k]
+    tot = X.sum(axis=1)
+    assert [int((tot > n).sum()) for n in range(int(tot.max()))] == fx["V"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_function_level_bit_exact(oracle, name):
+    fx = load_golden(name)
+    st = oracle.stats_from_lists(fx["U"], fx["V"])
+    for rec in fx["funcs"]:
+        g = rec["DE"]
+        a, hp = g["alpha"], g["hyperprior"]
+        assert oracle.logprob(a, st, hp) == g["logprob"]
+        assert oracle.total_loss(a, st, hp) == g["loss"]
+        grad = oracle.gradient(a, st, hp)
+        assert grad.tolist() == g["grad"]
+        hc = oracle.hconst(a, st)
+        hd = oracle.hdiag(a, st)
+        assert hc == g["hconst"]
+        assert hd.tolist() == g["hdiag"]
+        assert oracle.sq_vector_size(grad) == g["gradSq"]
+        if g["step"] is None:
+            with pytest.raises(ZeroDivisionError):
+                oracle.predicted_step(hc, hd, grad)
+        else:
+            assert oracle.predicted_step(hc, hd, grad).tolist() == g["step"]
+            assert oracle.predicted_step_alt(hc, hd, grad, a).tolist() == g["stepAlt"]
+        # NP variant: same maths, pairwise summation
+        n = rec["NP"]
+        np.testing.assert_allclose(oracle.total_loss(a, st, hp), n["loss"], rtol=1e-12)
+        np.testing.assert_allclose(grad, n["grad"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_find_priors_bit_exact(oracle, name):
+    fx = load_golden(name)
+    st = oracle.stats_from_lists(fx["U"], fx["V"])
+    n_checked = 0
+    for s in fx["solves"]:
+        if s["variant"] != "DE":
+            continue
+        if "raises" in s:
+            with pytest.raises(ZeroDivisionError):
+                oracle.find_priors(st, s["init"], s["iterations"], s["hyperprior"])
+            n_checked += 1
+            continue
+        out = oracle.find_priors(st, s["init"], s["iterations"], s["hyperprior"])
+        assert out["alpha"].tolist() == s["final"], (name, s["init_name"], s["hyperprior"])
+        assert out["exit"] == s["exit"]
+        assert out["n_iters"] == s["n_iters"]
+        assert out["n_evals"] == s["n_evals"]
+        assert out["trace_loss"].tolist() == [t["loss"] for t in s["trace"]]
+        assert out["trace_gradsq"].tolist() == [t["gradSq"] for t in s["trace"]]
+        assert out["trace_alpha"].tolist() == [t["priors"] for t in s["trace"]]
+        if "evals" in s:
+            m = min(len(out["eval_loss"]), len(s["evals"]))
+            assert out["eval_loss"][:m].tolist() == [e["loss"] for e in s["evals"][:m]]
+        assert oracle.total_loss(out["alpha"], st, s["hyperprior"]) == s["final_loss"]
+        n_checked += 1
+    assert n_checked > 0
+
+
+def test_np_variant_close(oracle):
+    """The NumPy port's answers (pairwise sums) stay within 1e-9 of the oracle's where the
+    branch history is the same (exit + iteration count equal)."""
+    for name in GOLDEN_CASES:
+        fx = load_golden(name)
+        st = oracle.stats_from_lists(fx["U"], fx["V"])
+        de = {(s["init_name"], s["hyperprior"]): s for s in fx["solves"] if s["variant"] == "DE"}
+        for s in fx["solves"]:
+            if s["variant"] != "NP" or "raises" in s:
+                continue
+            d = de[(s["init_name"], s["hyperprior"])]
+            if "raises" in d or d["n_evals"] != s["n_evals"] or d["exit"] == "C":
+                continue
+            np.testing.assert_allclose(d["final"], s["final"], rtol=1e-9)
+
+
+def test_cpt_variant_agrees():
+    """ConjugatePriorTools' original with no (Beta, W) prior gives the DE bits on test.csv."""
+    fx = load_golden("test_csv")
+    cpt = load_golden("cpt_test_csv")
+    de = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "cli"
+          and s["hyperprior"] == 0][0]
+    assert cpt["final"] == de["final"]
+    assert cpt["loss"] == de["final_loss"]
+
+
+def test_csr_rows_match_dense(oracle):
+    fx = load_golden("dirmult_k50")
+    X = fx["X"].astype(np.int32)
+    nz = X != 0
+    rowptr = np.concatenate([[0], np.cumsum(nz.sum(axis=1))]).astype(np.int64)
+    colidx = np.nonzero(nz)[1].astype(np.int32)
+    vals = X[nz].astype(np.int32)
+    st = oracle.append_rows_csr(rowptr, colidx, vals, fx["K"])
+    assert [list(map(int, u)) for u in st.U] == fx["U"]
+    assert list(map(int, st.V)) == fx["V"]
+    assert st.init_acc.tolist() == fx["init_acc"]
