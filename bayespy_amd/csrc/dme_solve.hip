@@ -1,0 +1,703 @@
+// dme_solve.hip — the Newton-Raphson solver of the Dirichlet-multinomial MLE on MI355X (gfx950).
+//
+// Replaces DirichletEstimation/dirichletMultinomialEstimation.py ("DE/dme.py"):
+//   dirichLogProb :16-29, priorGradient :32-48, priorHessianConst :52-53, priorHessianDiag :55-61,
+//   getPredictedStep :67-72, getPredictedStepAlt :76-80, testTrialPriors :97-102,
+//   sqVectorSize :104, findDirichletPriors :126-190.
+//
+// Structure.  The ragged statistics are cut into segments of SEG consecutive n of one column (the
+// row-total vector V is column K, evaluated at A = sum(alpha)).  One evaluation is
+//   eval_kernel  — one wave per segment: the fp64 sums  sum U*log(a+n),  sum U/(a+n),
+//                  sum U/(a+n)^2  with compensated (two-sum) accumulation and DPP wave reductions;
+//   step_kernel  — one workgroup: gathers the per-column sums in a fixed order, forms loss,
+//                  gradient and the diagonal-plus-rank-one Hessian, and advances the reference's
+//                  state machine (strict-< Newton acceptance, log-space trial, x0.9 step halving,
+//                  exits A/B/C) — every decision is taken here, on the device.
+// A loss evaluation at a trial point also yields gradient and Hessian there, so an accepted Newton
+// step costs exactly one evaluation.  The host enqueues batches of (eval, step) pairs and polls a
+// done flag once per batch; kernels after convergence return at once.  A kernel boundary
+// (~1.5 us on MI355X) is cheaper than an in-kernel grid barrier (~4-7 us), which is why the loop is
+// a chain of launches and not one persistent kernel.  No MFMA: nothing here is a dense contraction.
+#include <math.h>
+
+#include "dme_common.h"
+
+namespace {
+
+constexpr int SEG = 256;         // terms per segment: 4 per lane
+constexpr int STEP_BLOCK = 1024;
+constexpr int STEP_WAVES = STEP_BLOCK / 64;
+constexpr int EVAL_BLOCK = 256;
+
+enum Phase : long long { PH_INIT = 0, PH_NEWTON = 1, PH_LOGSPACE = 2, PH_HALVING = 3, PH_EVALONLY = 4 };
+
+struct Ctrl {
+    long long done;
+    long long phase;
+    long long count;
+    long long n_evals;
+    long long exit_reason;
+    long long error;
+    long long nseg;
+    long long launches;
+    long long trial_valid;
+    long long branch;
+    double currentLoss;
+    double learnRate;
+    double A_trial;
+    double hconst_cur;
+    double pad[2];
+};
+static_assert(sizeof(Ctrl) % 16 == 0, "Ctrl must stay 16-byte sized");
+
+struct Partial {  // per segment
+    double s0hi, s0lo, s1hi, s1lo, s2, pad;
+};
+
+// workspace carve-up (all offsets 256-byte aligned)
+struct Ws {
+    Ctrl* ctrl;
+    int* seg_k;
+    int* seg_start;
+    long long* segfirst;  // [K+2]
+    Partial* part;
+    double* alpha_cur;
+    double* g_cur;
+    double* d_cur;
+    double* alpha_trial;
+    double* g_trial;
+    double* d_trial;
+    long long nseg_max;
+    long long bytes;
+};
+
+inline long long align256(long long x) { return (x + 255) & ~255LL; }
+
+inline long long nseg_bound(long long K, long long ldU, long long capV) {
+    return K * ((ldU + SEG - 1) / SEG + 1) + (capV + SEG - 1) / SEG + 2;
+}
+
+Ws carve(void* base, long long K, long long ldU, long long capV) {
+    Ws w{};
+    long long off = 0;
+    char* b = (char*)base;
+    auto take = [&](long long bytes) {
+        char* p = b ? b + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    w.nseg_max = nseg_bound(K, ldU, capV);
+    w.ctrl = (Ctrl*)take(sizeof(Ctrl));
+    w.seg_k = (int*)take(w.nseg_max * 4);
+    w.seg_start = (int*)take(w.nseg_max * 4);
+    w.segfirst = (long long*)take((K + 2) * 8);
+    w.part = (Partial*)take(w.nseg_max * (long long)sizeof(Partial));
+    w.alpha_cur = (double*)take(K * 8);
+    w.g_cur = (double*)take(K * 8);
+    w.d_cur = (double*)take(K * 8);
+    w.alpha_trial = (double*)take(K * 8);
+    w.g_trial = (double*)take(K * 8);
+    w.d_trial = (double*)take(K * 8);
+    w.bytes = off;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide reductions (STEP_BLOCK threads), deterministic order
+// ---------------------------------------------------------------------------------------------
+struct BlockShared {
+    DmeAcc acc[STEP_WAVES];
+    double dbl[STEP_WAVES];
+    int flag[STEP_WAVES];
+};
+
+__device__ __forceinline__ DmeAcc block_sum_acc(DmeAcc v, BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = dme_wave_sum_acc(v);
+    if (lane == 0) sh.acc[wave] = v;
+    __syncthreads();
+    DmeAcc r = sh.acc[0];
+#pragma unroll
+    for (int w = 1; w < STEP_WAVES; ++w) r.add(sh.acc[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ double block_sum(double v, BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = dme_wave_sum_f64(v);
+    if (lane == 0) sh.dbl[wave] = v;
+    __syncthreads();
+    double r = sh.dbl[0];
+#pragma unroll
+    for (int w = 1; w < STEP_WAVES; ++w) r = __dadd_rn(r, sh.dbl[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ bool block_any(bool p, BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int any = __any(p);
+    if (lane == 0) sh.flag[wave] = any;
+    __syncthreads();
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < STEP_WAVES; ++w) r |= sh.flag[w];
+    __syncthreads();
+    return r != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment table: column k (k == K is V) gets ceil(len_k / SEG) segments, listed in column order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(STEP_BLOCK) void build_segments_kernel(
+    Ctrl* ctrl, const long long* lenU, const long long* lenV, long long K, long long ldU,
+    long long capV, int* seg_k, int* seg_start, long long* segfirst, long long nseg_max) {
+    __shared__ long long wsum[STEP_WAVES];
+    __shared__ long long base_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long ncol = K + 1;
+    const long long per = (ncol + STEP_BLOCK - 1) / STEP_BLOCK;
+    const long long k0 = (long long)tid * per, k1 = min(ncol, k0 + per);
+    auto len_of = [&](long long k) {
+        long long L = k < K ? lenU[k] : lenV[0];
+        const long long cap = k < K ? ldU : capV;
+        if (L < 0) L = 0;
+        if (L > cap) L = cap;
+        return L;
+    };
+    long long mine = 0;
+    for (long long k = k0; k < k1; ++k) mine += (len_of(k) + SEG - 1) / SEG;
+    long long sc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long up = __shfl_up(sc, d);
+        if (lane >= d) sc += up;
+    }
+    if (lane == 63) wsum[wave] = sc;
+    __syncthreads();
+    long long before = 0, total = 0;
+    for (int w = 0; w < STEP_WAVES; ++w) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
+    }
+    long long pos = before + sc - mine;
+    for (long long k = k0; k < k1; ++k) {
+        segfirst[k] = pos;
+        const long long L = len_of(k);
+        for (long long st = 0; st < L; st += SEG) {
+            if (pos < nseg_max) {
+                seg_k[pos] = (int)k;
+                seg_start[pos] = (int)st;
+            }
+            ++pos;
+        }
+    }
+    if (tid == 0) {
+        segfirst[ncol] = total;
+        ctrl->nseg = total < nseg_max ? total : nseg_max;
+    }
+    (void)base_sh;
+}
+
+// ---------------------------------------------------------------------------------------------
+// evaluation: one wave per segment
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(
+    const Ctrl* ctrl, const int* seg_k, const int* seg_start, const double* Uf, long long ldU,
+    const long long* lenU, const double* Vf, long long capV, const long long* lenV, long long K,
+    const double* alpha, Partial* part) {
+    if (ctrl->done || !ctrl->trial_valid) return;
+    const int lane = threadIdx.x & 63;
+    const long long nseg = ctrl->nseg;
+    const long long wave0 = ((long long)blockIdx.x * EVAL_BLOCK + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * EVAL_BLOCK) >> 6;
+    for (long long s = wave0; s < nseg; s += nwaves) {
+        const long long k = seg_k[s];
+        const long long st = seg_start[s];
+        long long L = k < K ? lenU[k] : lenV[0];
+        const long long cap = k < K ? ldU : capV;
+        if (L > cap) L = cap;
+        const double* u = k < K ? Uf + k * ldU : Vf;
+        const double a = k < K ? alpha[k] : ctrl->A_trial;
+        long long end = st + SEG < L ? st + SEG : L;
+        DmeAcc s0{0.0, 0.0}, s1{0.0, 0.0};
+        double s2 = 0.0;
+        for (long long n = st + lane; n < end; n += 64) {
+            const double un = u[n];
+            const double x = __dadd_rn(a, (double)n);
+            s0.add(__dmul_rn(un, log(x)));                 // U[k][n] * log(alpha_k + n)   :21 / :25
+            s1.add(__ddiv_rn(un, x));                      // U[k][n] / (alpha_k + n)      :42 / :37
+            s2 = __dadd_rn(s2, __ddiv_rn(un, __dmul_rn(x, x)));  // U/(alpha_k+n)^2       :60 / :53
+        }
+        s0 = dme_wave_sum_acc(s0);
+        s1 = dme_wave_sum_acc(s1);
+        s2 = dme_wave_sum_f64(s2);
+        if (lane == 0) {
+            Partial p{s0.hi, s0.lo, s1.hi, s1.lo, s2, 0.0};
+            part[s] = p;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared device pieces of the step kernel
+// ---------------------------------------------------------------------------------------------
+struct Gathered {
+    DmeAcc logsum;  // sum_k sum_n U log(.)     (block total)
+    DmeAcc t0, t1;  // V sums
+    double t2;
+};
+
+// Per-column sums at the evaluated point -> g_out[k], d_out[k]; returns the block totals.
+__device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambda, double* g_out,
+                                double* d_out, BlockShared& sh) {
+    Gathered G;
+    const int tid = threadIdx.x;
+    // V = column K
+    {
+        const long long f = w.segfirst[K], l = w.segfirst[K + 1];
+        DmeAcc a0{0, 0}, a1{0, 0};
+        double a2 = 0.0;
+        for (long long s = f + tid; s < l; s += STEP_BLOCK) {
+            const Partial p = w.part[s];
+            a0.add(DmeAcc{p.s0hi, p.s0lo});
+            a1.add(DmeAcc{p.s1hi, p.s1lo});
+            a2 = __dadd_rn(a2, p.s2);
+        }
+        G.t0 = block_sum_acc(a0, sh);
+        G.t1 = block_sum_acc(a1, sh);
+        G.t2 = block_sum(a2, sh);
+    }
+    const double termToSubtract = G.t1.value();
+    const double hs = __dmul_rn(lambda, A);  // hyperprior * sum(priorList)   DE/dme.py:46
+    DmeAcc ls{0, 0};
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const long long f = w.segfirst[k], l = w.segfirst[k + 1];
+        DmeAcc a0{0, 0}, a1{0, 0};
+        double a2 = 0.0;
+        for (long long s = f; s < l; ++s) {
+            const Partial p = w.part[s];
+            a0.add(DmeAcc{p.s0hi, p.s0lo});
+            a1.add(DmeAcc{p.s1hi, p.s1lo});
+            a2 = __dadd_rn(a2, p.s2);
+        }
+        ls.add(a0);
+        double g = __dsub_rn(a1.value(), termToSubtract);  // :45
+        g = __dadd_rn(g, hs);                              // :46
+        g_out[k] = g;
+        d_out[k] = -a2;                                    // :60
+    }
+    G.logsum = block_sum_acc(ls, sh);
+    return G;
+}
+
+__device__ __forceinline__ double loss_from(const Gathered& G, double A, double lambda) {
+    // total = sum U log - sum V log + sum(alpha)*lambda ; loss = -total     DE/dme.py:21-29, :84
+    DmeAcc t = G.logsum;
+    DmeAcc neg{-G.t0.hi, -G.t0.lo};
+    t.add(neg);
+    t.add(__dmul_rn(A, lambda));
+    return -t.value();
+}
+
+// getPredictedStep (DE/dme.py:67-72) applied to alpha: trial = alpha + step.
+// Returns false (zero division) where Python raises.
+__device__ bool newton_trial(const double* alpha, const double* g, const double* d, double hconst,
+                             long long K, double* trial, double* step_out, BlockShared& sh) {
+    const int tid = threadIdx.x;
+    bool zero = false;
+    double num = 0.0, den = 0.0;
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double dk = d[k];
+        if (dk == 0.0) { zero = true; continue; }
+        num = __dadd_rn(num, __ddiv_rn(g[k], dk));
+        den = __dadd_rn(den, __ddiv_rn(1.0, dk));
+    }
+    if (block_any(zero, sh) || hconst == 0.0) return false;
+    const double numSum = block_sum(num, sh), denSum = block_sum(den, sh);
+    const double dd = __dadd_rn(__ddiv_rn(1.0, hconst), denSum);
+    if (dd == 0.0) return false;
+    const double b = __ddiv_rn(numSum, dd);
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double st = __ddiv_rn(__dsub_rn(b, g[k]), d[k]);
+        if (step_out) step_out[k] = st;
+        if (trial) trial[k] = __dadd_rn(alpha[k], st);
+    }
+    return true;
+}
+
+// getPredictedStepAlt (DE/dme.py:76-80); trial = alpha * exp(step) with the bare-except of :168-171.
+__device__ bool logspace_trial(const double* alpha, const double* g, const double* d, double hconst,
+                               long long K, double* trial, double* step_out, BlockShared& sh) {
+    const int tid = threadIdx.x;
+    bool zero = false;
+    double zs = 0.0, ss = 0.0;
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double x = __dadd_rn(g[k], __dmul_rn(alpha[k], d[k]));  // :77
+        if (x == 0.0) { zero = true; continue; }
+        zs = __dadd_rn(zs, __ddiv_rn(alpha[k], x));
+        ss = __dadd_rn(ss, __ddiv_rn(__dmul_rn(alpha[k], g[k]), x));
+    }
+    if (block_any(zero, sh) || hconst == 0.0) return false;
+    const double Z = __dadd_rn(__ddiv_rn(1.0, hconst), block_sum(zs, sh));  // :78
+    const double S = block_sum(ss, sh);                                     // :79
+    if (Z == 0.0) return false;
+    const double soz = __ddiv_rn(S, Z);
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double x = __dadd_rn(g[k], __dmul_rn(alpha[k], d[k]));
+        const double st = __ddiv_rn(__dsub_rn(soz, g[k]), x);  // :80
+        if (step_out) step_out[k] = st;
+        if (trial) {
+            const double e = exp(st);
+            // math.exp raises OverflowError on overflow; the bare except keeps the prior (:170-171)
+            trial[k] = (isinf(e) && !isinf(st)) ? alpha[k] : __dmul_rn(alpha[k], e);
+        }
+    }
+    return true;
+}
+
+// sum(trial) and the positivity test of testTrialPriors (DE/dme.py:98-100)
+__device__ void finish_trial(Ctrl* ctrl, const double* trial, long long K, BlockShared& sh) {
+    const int tid = threadIdx.x;
+    double a = 0.0;
+    bool bad = false;
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double t = trial[k];
+        a = __dadd_rn(a, t);
+        if (t <= 0.0) bad = true;
+    }
+    const double A = block_sum(a, sh);
+    const bool anybad = block_any(bad, sh);
+    if (tid == 0) {
+        ctrl->A_trial = A;
+        ctrl->trial_valid = anybad ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* alpha, long long K,
+                                                           long long phase) {
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        Ctrl* c = w.ctrl;
+        c->done = 0; c->phase = phase; c->count = 0; c->n_evals = 0; c->exit_reason = 0;
+        c->error = 0; c->launches = 0; c->branch = 0; c->currentLoss = 0.0; c->learnRate = 1.0;
+        c->hconst_cur = 0.0;
+    }
+    for (long long k = tid; k < K; k += STEP_BLOCK) w.alpha_trial[k] = alpha[k];
+    __syncthreads();
+    finish_trial(w.ctrl, w.alpha_trial, K, sh);
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, long long iterations,
+                                                          double lambda, double* trace,
+                                                          double* trace_alpha, long long trace_cap,
+                                                          double* alpha_out, long long* result,
+                                                          double* final_loss) {
+    __shared__ BlockShared sh;
+    Ctrl* c = w.ctrl;
+    if (c->done) return;
+    const int tid = threadIdx.x;
+    const long long phase = c->phase;
+    const bool valid = c->trial_valid != 0;
+    const double A = c->A_trial;
+    double currentLoss = c->currentLoss;
+    double learnRate = c->learnRate;
+    long long count = c->count;
+    long long n_evals = c->n_evals;
+    long long branch = c->branch;
+
+    double lossT = INFINITY;
+    double hconstT = 0.0;
+    if (valid) {
+        const Gathered G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
+        lossT = loss_from(G, A, lambda);
+        hconstT = G.t2;
+        n_evals += 1;
+    }
+
+    auto finish = [&](long long reason, long long err) {
+        // returned priors are alpha_cur
+        for (long long k = tid; k < K; k += STEP_BLOCK) alpha_out[k] = w.alpha_cur[k];
+        if (tid == 0) {
+            c->done = 1; c->exit_reason = reason; c->error = err; c->count = count;
+            c->n_evals = n_evals; c->currentLoss = currentLoss;
+            result[0] = reason; result[1] = count; result[2] = n_evals; result[3] = err;
+            result[4] = c->launches + 1;
+            if (final_loss) final_loss[0] = currentLoss;
+        }
+    };
+    auto store_state = [&](long long new_phase) {
+        if (tid == 0) {
+            c->phase = new_phase; c->count = count; c->n_evals = n_evals;
+            c->currentLoss = currentLoss; c->learnRate = learnRate; c->branch = branch;
+            c->launches += 1;
+        }
+    };
+
+    bool accept = false;
+    if (phase == PH_INIT) {
+        if (!valid) {  // math.log(x <= 0) -> ValueError at DE/dme.py:131
+            for (long long k = tid; k < K; k += STEP_BLOCK) w.alpha_cur[k] = w.alpha_trial[k];
+            finish(0, DME_ERR_MATH_DOMAIN);
+            return;
+        }
+        currentLoss = lossT;  // :131
+        accept = true;
+        branch = 0;
+    } else if (phase == PH_NEWTON) {
+        if (lossT < currentLoss) {  // :160 (strict)
+            currentLoss = lossT;
+            accept = true;
+            branch = 1;
+        } else {
+            // :165-172 log-space trial from the CURRENT point's gradient / Hessian
+            const bool ok = logspace_trial(w.alpha_cur, w.g_cur, w.d_cur, c->hconst_cur, K,
+                                           w.alpha_trial, nullptr, sh);
+            if (!ok) { finish(0, DME_ERR_ZERO_DIVISION); return; }
+            __syncthreads();
+            finish_trial(c, w.alpha_trial, K, sh);
+            learnRate = 1.0;  // :175
+            store_state(PH_LOGSPACE);
+            return;
+        }
+    } else {  // PH_LOGSPACE / PH_HALVING: the while loop of :176-180
+        if (lossT > currentLoss) {
+            learnRate = __dmul_rn(learnRate, 0.9);
+            for (long long k = tid; k < K; k += STEP_BLOCK)
+                w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __dmul_rn(w.g_cur[k], learnRate));
+            __syncthreads();
+            finish_trial(c, w.alpha_trial, K, sh);
+            store_state(PH_HALVING);
+            return;
+        }
+        if (learnRate < 9.5367431640625e-07) {  // 2 ** -20, :134, :182-184
+            finish(2, 0);
+            return;
+        }
+        currentLoss = lossT;  // :186-187
+        accept = true;
+        branch = (phase == PH_LOGSPACE) ? 2 : 3;
+    }
+
+    if (accept) {
+        for (long long k = tid; k < K; k += STEP_BLOCK) {
+            w.alpha_cur[k] = w.alpha_trial[k];
+            w.g_cur[k] = w.g_trial[k];
+            w.d_cur[k] = w.d_trial[k];
+        }
+        if (tid == 0) c->hconst_cur = hconstT;
+    }
+    const double hconst = hconstT;  // == hconst_cur after an accept
+
+    // ---- top of the while loop, DE/dme.py:137-150 ---------------------------------------------
+    if (count >= iterations) {  // :137 / :189-190
+        finish(3, 0);
+        return;
+    }
+    count += 1;
+    double gs = 0.0;
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double g = w.g_cur[k];
+        gs = __dadd_rn(gs, __dmul_rn(g, g));
+    }
+    const double gradSq = block_sum(gs, sh);  // :142
+    if (count - 1 < trace_cap) {
+        if (trace && tid == 0) {
+            double* t = trace + (count - 1) * 4;
+            t[0] = currentLoss; t[1] = gradSq; t[2] = (double)branch; t[3] = learnRate;
+        }
+        if (trace_alpha)
+            for (long long k = tid; k < K; k += STEP_BLOCK)
+                trace_alpha[(count - 1) * K + k] = w.alpha_cur[k];
+    }
+    if (gradSq < 0.0009765625) {  // 2 ** -10, :133, :145-147
+        finish(1, 0);
+        return;
+    }
+    const bool ok = newton_trial(w.alpha_cur, w.g_cur, w.d_cur, hconst, K, w.alpha_trial, nullptr, sh);
+    if (!ok) { finish(0, DME_ERR_ZERO_DIVISION); return; }
+    __syncthreads();
+    finish_trial(c, w.alpha_trial, K, sh);
+    store_state(PH_NEWTON);
+}
+
+// dme_eval epilogue: publish the evaluated quantities
+__global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long long K, double lambda,
+                                                                  double* out_scalars,
+                                                                  double* out_grad,
+                                                                  double* out_hdiag) {
+    __shared__ BlockShared sh;
+    Ctrl* c = w.ctrl;
+    const int tid = threadIdx.x;
+    const double A = c->A_trial;
+    if (!c->trial_valid) {  // some alpha <= 0: math.log would raise; nothing was evaluated
+        for (long long k = tid; k < K; k += STEP_BLOCK) {
+            if (out_grad) out_grad[k] = NAN;
+            if (out_hdiag) out_hdiag[k] = NAN;
+        }
+        if (tid == 0) { out_scalars[0] = NAN; out_scalars[1] = NAN; out_scalars[2] = A; out_scalars[3] = NAN; }
+        return;
+    }
+    const Gathered G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
+    const double loss = loss_from(G, A, lambda);
+    double gs = 0.0;
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        const double g = w.g_trial[k];
+        gs = __dadd_rn(gs, __dmul_rn(g, g));
+        if (out_grad) out_grad[k] = g;
+        if (out_hdiag) out_hdiag[k] = w.d_trial[k];
+    }
+    const double gradSq = block_sum(gs, sh);
+    if (tid == 0) {
+        out_scalars[0] = -loss;
+        out_scalars[1] = G.t2;
+        out_scalars[2] = A;
+        out_scalars[3] = gradSq;
+    }
+}
+
+__global__ __launch_bounds__(STEP_BLOCK) void predicted_step_kernel(double hconst,
+                                                                    const double* hdiag,
+                                                                    const double* grad,
+                                                                    const double* alphas,
+                                                                    long long K, double* step,
+                                                                    long long* status, int alt) {
+    __shared__ BlockShared sh;
+    const bool ok = alt ? logspace_trial(alphas, grad, hdiag, hconst, K, nullptr, step, sh)
+                        : newton_trial(nullptr, grad, hdiag, hconst, K, nullptr, step, sh);
+    if (threadIdx.x == 0) status[0] = ok ? 0 : DME_ERR_ZERO_DIVISION;
+}
+
+int check_common(const double* Uf, long long ldU, const long long* lenU, const double* Vf,
+                 long long capV, const long long* lenV, long long K, void* workspace,
+                 long long workspace_bytes, Ws* w) {
+    DME_REQUIRE(K >= 1 && ldU >= 1 && capV >= 1, "bad shape K=%lld ldU=%lld capV=%lld", K, ldU, capV);
+    DME_REQUIRE(K < (1LL << 31) && ldU < (1LL << 31) && capV < (1LL << 31), "shape too large");
+    DME_REQUIRE(Uf && lenU && Vf && lenV, "null statistics pointer");
+    DME_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0,
+                "workspace must be a 256-byte aligned device pointer");
+    *w = carve(workspace, K, ldU, capV);
+    if (workspace_bytes < w->bytes)
+        return dme_set_error(DME_ERR_WORKSPACE, "solver workspace: need %lld bytes, got %lld",
+                             w->bytes, workspace_bytes);
+    return DME_OK;
+}
+
+unsigned eval_grid(long long nseg_max) {
+    long long waves_per_block = EVAL_BLOCK / 64;
+    long long g = (nseg_max + waves_per_block - 1) / waves_per_block;
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    const long long cap = (long long)cus * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int64_t dme_solver_workspace_bytes(int64_t K, int64_t ldU, int64_t capV) {
+    if (K < 1 || ldU < 1 || capV < 1) return -1;
+    return carve(nullptr, K, ldU, capV).bytes;
+}
+
+extern "C" int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                        int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                        double hyperprior, double* out_scalars, double* out_grad,
+                        double* out_hdiag, void* workspace, int64_t workspace_bytes, void* stream) {
+    Ws w;
+    int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
+                          workspace, workspace_bytes, &w);
+    if (rc) return rc;
+    DME_REQUIRE(alpha && out_scalars, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, alpha, (long long)K,
+                       (long long)PH_EVALONLY);
+    hipLaunchKernelGGL(build_segments_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w.ctrl,
+                       (const long long*)lenU, (const long long*)lenV, (long long)K, (long long)ldU,
+                       (long long)capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
+    // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
+    hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
+                       w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
+                       (long long)capV, (const long long*)lenV, (long long)K, w.alpha_trial, w.part);
+    hipLaunchKernelGGL(publish_eval_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (long long)K,
+                       hyperprior, out_scalars, out_grad, out_hdiag);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_predicted_step(double hconst, const double* hdiag, const double* grad, int64_t K,
+                                  double* step, int64_t* status, void* stream) {
+    DME_REQUIRE(K >= 1 && hdiag && grad && step && status, "bad arguments");
+    hipLaunchKernelGGL(predicted_step_kernel, dim3(1), dim3(STEP_BLOCK), 0, (hipStream_t)stream,
+                       hconst, hdiag, grad, (const double*)nullptr, (long long)K, step,
+                       (long long*)status, 0);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_predicted_step_alt(double hconst, const double* hdiag, const double* grad,
+                                      const double* alphas, int64_t K, double* step,
+                                      int64_t* status, void* stream) {
+    DME_REQUIRE(K >= 1 && hdiag && grad && alphas && step && status, "bad arguments");
+    hipLaunchKernelGGL(predicted_step_kernel, dim3(1), dim3(STEP_BLOCK), 0, (hipStream_t)stream,
+                       hconst, hdiag, grad, alphas, (long long)K, step, (long long*)status, 1);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                         int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                         int64_t iterations, double hyperprior, double* trace, double* trace_alpha,
+                         int64_t trace_cap, int64_t* result, double* final_loss, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+    Ws w;
+    int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
+                          workspace, workspace_bytes, &w);
+    if (rc) return rc;
+    DME_REQUIRE(alpha && result, "null pointer");
+    DME_REQUIRE(iterations >= 0 && trace_cap >= 0, "negative iterations / trace_cap");
+    hipStream_t s = (hipStream_t)stream;
+    DME_HIP_CHECK(hipMemsetAsync(result, 0, 8 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)alpha,
+                       (long long)K, (long long)PH_INIT);
+    hipLaunchKernelGGL(build_segments_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w.ctrl,
+                       (const long long*)lenU, (const long long*)lenV, (long long)K, (long long)ldU,
+                       (long long)capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
+    DME_HIP_CHECK(hipGetLastError());
+    const unsigned grid = eval_grid(w.nseg_max);
+    // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
+    const long long max_pairs = (iterations + 2) * 450 + 16;
+    long long pairs = 0;
+    int batch = 10;
+    long long done = 0;
+    while (!done) {
+        for (int i = 0; i < batch; ++i) {
+            hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, w.ctrl, w.seg_k,
+                               w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
+                               (long long)capV, (const long long*)lenV, (long long)K,
+                               w.alpha_trial, w.part);
+            hipLaunchKernelGGL(step_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (long long)K,
+                               (long long)iterations, hyperprior, trace, trace_alpha,
+                               (long long)trace_cap, alpha, (long long*)result, final_loss);
+        }
+        pairs += batch;
+        DME_HIP_CHECK(hipGetLastError());
+        DME_HIP_CHECK(hipMemcpyAsync(&done, &w.ctrl->done, sizeof(long long), hipMemcpyDeviceToHost, s));
+        DME_HIP_CHECK(hipStreamSynchronize(s));
+        if (!done && pairs > max_pairs)
+            return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld evaluations", pairs);
+        if (batch < 64) batch *= 2;
+    }
+    long long res[4] = {0, 0, 0, 0};
+    DME_HIP_CHECK(hipMemcpyAsync(res, result, sizeof(res), hipMemcpyDeviceToHost, s));
+    DME_HIP_CHECK(hipStreamSynchronize(s));
+    if (res[3] == DME_ERR_ZERO_DIVISION)
+        return dme_set_error(DME_ERR_ZERO_DIVISION, "float division by zero (an all-zero column or empty V)");
+    if (res[3] == DME_ERR_MATH_DOMAIN)
+        return dme_set_error(DME_ERR_MATH_DOMAIN, "math domain error (non-positive initial alpha)");
+    if (res[3] != 0) return dme_set_error(DME_ERR_INTERNAL, "solver error %lld", res[3]);
+    return DME_OK;
+}

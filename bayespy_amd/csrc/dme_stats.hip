@@ -1,0 +1,555 @@
+// dme_stats.hip — statistics build for the Dirichlet-multinomial MLE on MI355X (gfx950).
+//
+// Replaces, for a whole count matrix at once, the reference's per-row
+//   CompressedRowData.appendRow       DirichletEstimation/dirichletMultinomialEstimation.py:113-123
+//   the CLI's mean accumulator        DirichletEstimation/findDirichletPrior.py:87-89
+// by one streaming pass that builds VALUE histograms
+//   hist[k][v] = #{i : x_ik == v},   histV[t] = #{i : sum_k x_ik == t}
+// (dme_scan.hip turns them into U[k][n] = #{i : x_ik > n}, V[n] = #{i : n_i > n}).
+//
+// Kernel shape (HBM-bound; algorithmic bytes = N*K*sizeof(elem), read exactly once):
+//   * one 64-lane wave owns whole rows: a lane loads up to J vectors of E elements (16 B when the
+//     row pitch allows) of one row, so the row total is a DPP wave reduction and X is read once;
+//     when a row is shorter than a wave (C = K/E < 64) a wave carries R = 64/C rows side by side;
+//   * a lane keeps the same columns for every row, so the fp64 mean accumulators live in VGPRs and
+//     are combined in a FIXED order (waves in LDS, workgroups in a second kernel): the result is
+//     bit-reproducible run to run;
+//   * counts 1..B go to an LDS-privatised histogram of packed 16-bit counters (two columns per
+//     32-bit word, ds_add_u32, a workgroup handles <= 65535 rows so a counter cannot overflow);
+//     zero cells hit no real bin: a whole zero dword is skipped, a zero half of a non-zero dword is
+//     added to a sink row that is never flushed, so the hot loop has no per-element branch;
+//   * counts > B (rare) and row totals >= TB go straight to 64-bit global atomics;
+//   * at the end the workgroup flushes its non-zero LDS counters with 64-bit global atomics.
+#include <type_traits>
+
+#include "dme_common.h"
+
+namespace {
+
+struct StatsArgs {
+    const void* X;
+    long long N, K, ld;
+    u64* hist;
+    long long nbins;
+    u64* histV;
+    long long tbins;
+    double* part;  // [gridDim.x][K] per-workgroup mean accumulators
+    u64* status;
+    int rows_per_wg;
+    int C;    // vectors (chunks) per row = K / E
+    int R;    // rows carried side by side by one wave (1 unless MULTI)
+    int B;    // LDS-privatised count bins 1..B (row 0 of the LDS histogram is the sink)
+    int BRW;  // 32-bit words per LDS bin row
+    int TB;   // LDS-privatised row-total bins [0, TB)
+};
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int BYTES, int ND>
+__device__ __forceinline__ void load_chunk(const void* p, u32 (&d)[ND]) {
+    if constexpr (BYTES == 16) {
+        u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    } else if constexpr (BYTES == 8) {
+        u32x2 v = __builtin_nontemporal_load((const u32x2*)p);
+        d[0] = v.x; d[1] = v.y;
+    } else if constexpr (BYTES == 4) {
+        d[0] = __builtin_nontemporal_load((const u32*)p);
+    } else {
+        d[0] = (u32)__builtin_nontemporal_load((const unsigned short*)p);
+    }
+}
+
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(x, y));
+}
+
+template <int J, int E>
+struct StatsCfg {
+    static constexpr int BLOCK = (J * E > 16) ? 512 : 1024;
+    static constexpr int RB = (J <= 2) ? 4 : (J == 4 ? 2 : 1);  // row groups in flight per wave
+};
+
+// T: element type (unsigned short | int).  E: elements per vector load.  J: vectors per lane and
+// row.  MULTI: a wave carries R = 64/C rows at once (then J == 1).
+template <typename T, int E, int J, bool MULTI>
+__global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
+    constexpr bool IS16 = sizeof(T) == 2;
+    constexpr int BYTES = E * (int)sizeof(T);
+    constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
+    constexpr int PW = E >= 2 ? E / 2 : 1;          // LDS words per vector (2 columns per word)
+    constexpr int BLOCK = StatsCfg<J, E>::BLOCK;
+    constexpr int W = BLOCK / 64;
+    constexpr int RB = StatsCfg<J, E>::RB;
+    typedef typename std::conditional<IS16, u32, u64>::type SumT;
+
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = a.C;
+    const int R = MULTI ? a.R : 1;
+    const int r = MULTI ? lane / C : 0;
+    const int c = MULTI ? lane - r * C : lane;
+    const bool lane_has_row = MULTI ? (r < R) : true;
+    const int CW = MULTI ? C : 64;
+    const int B = a.B, BRW = a.BRW, TB = a.TB;
+    u32* ldsV = lds;
+    u32* ldsH = lds + TB;
+    const int nwords = TB + (B + 1) * BRW;
+    for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
+    __syncthreads();
+
+    double acc[J][E];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[j][e] = 0.0;
+    u32 n_over_cells = 0, n_over_rows = 0, n_neg = 0;
+    u64 maxv = 0, maxt = 0;
+
+    const long long row0 = (long long)blockIdx.x * a.rows_per_wg;
+    const long long row1 = min(a.N, row0 + (long long)a.rows_per_wg);
+    const long long nrows = row1 > row0 ? row1 - row0 : 0;
+    const long long ngroups = (nrows + R - 1) / R;
+    const u32 binRowBytes = (u32)BRW * 4u;
+    // byte offset of this lane's word 0 inside a bin row; word (j, p) is (j*PW + p)*CW words on.
+    const u32 laneWordByte = (u32)c * 4u;
+    char* ldsHb = (char*)ldsH;
+    const T* Xp = (const T*)a.X;
+    const long long nbins = a.nbins, tbins = a.tbins;
+
+    for (long long g0 = wave; g0 < ngroups; g0 += (long long)W * RB) {
+        u32 d[RB][J][ND];
+        bool ok[RB];
+        long long rowi[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const long long g = g0 + (long long)rb * W;
+            rowi[rb] = row0 + g * R + r;
+            ok[rb] = (g < ngroups) && lane_has_row && (rowi[rb] < row1);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = c + 64 * j;
+                if (ok[rb] && chunk < C) {
+                    load_chunk<BYTES, ND>(Xp + rowi[rb] * a.ld + (long long)chunk * E, d[rb][j]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) d[rb][j][q] = 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (g0 + (long long)rb * W >= ngroups) break;  // wave-uniform
+            // ---- row total ---------------------------------------------------------------
+            SumT s = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int q = 0; q < ND; ++q) {
+                    if constexpr (IS16) {
+                        s = __builtin_amdgcn_sad_u16(d[rb][j][q], 0u, s);
+                    } else {
+                        const int v = (int)d[rb][j][q];
+                        s += (SumT)(v > 0 ? v : 0);
+                    }
+                }
+            SumT total;
+            if constexpr (MULTI) {
+                SumT incl = s;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    SumT up = __shfl_up(incl, dd);
+                    if (c >= dd) incl += up;
+                }
+                int last = r * C + C - 1;
+                total = __shfl(incl, last > 63 ? 63 : last);
+            } else {
+                if constexpr (IS16) total = dme_wave_sum_u32(s);
+                else total = dme_wave_sum_u64(s);
+            }
+            // ---- row-total histogram (one lane per row) -------------------------------------
+            if (ok[rb] && c == 0 && total > 0) {
+                if ((u64)total > maxt) maxt = total;
+                if ((u64)total < (u64)TB) atomicAdd(&ldsV[(u32)total], 1u);
+                else if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
+                else n_over_rows++;
+            }
+            // weightForMean = 1.0 / (1.0 + sumData)            (DE/fdp.py:88)
+            const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+            // ---- cells --------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = c + 64 * j;
+                if constexpr (IS16) {
+                    // rare path first: any count > B in this vector?  (packed 16-bit max)
+                    u32 m = d[rb][j][0];
+#pragma unroll
+                    for (int q = 1; q < ND; ++q) m = pk_max_u16(m, d[rb][j][q]);
+                    const u32 mlo = m & 0xffffu, mhi = (E >= 2) ? (m >> 16) : 0u;
+                    const u32 mx = mlo > mhi ? mlo : mhi;
+                    if (mx > (u32)B) {
+                        if ((u64)mx > maxv) maxv = mx;
+#pragma unroll
+                        for (int q = 0; q < ND; ++q)
+#pragma unroll
+                            for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
+                                const u32 v = h ? (d[rb][j][q] >> 16) : (d[rb][j][q] & 0xffffu);
+                                if (v > (u32)B) {
+                                    const long long k = (long long)chunk * E + 2 * q + h;
+                                    if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                    else n_over_cells++;
+                                    acc[j][2 * q + h] =
+                                        __dadd_rn(acc[j][2 * q + h], __dmul_rn((double)v, w));
+                                    d[rb][j][q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
+                                }
+                            }
+                    } else if ((u64)mx > maxv) {
+                        maxv = mx;
+                    }
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) {
+                        const u32 dw = d[rb][j][q];
+                        if (dw != 0) {
+                            const u32 lo = dw & 0xffffu;
+                            const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
+                            atomicAdd((u32*)(ldsHb + lo * binRowBytes + wb), 1u);
+                            acc[j][2 * q] = __dadd_rn(acc[j][2 * q], __dmul_rn((double)lo, w));
+                            if constexpr (E >= 2) {
+                                const u32 hi = dw >> 16;
+                                atomicAdd((u32*)(ldsHb + hi * binRowBytes + wb), 65536u);
+                                acc[j][2 * q + 1] =
+                                    __dadd_rn(acc[j][2 * q + 1], __dmul_rn((double)hi, w));
+                            }
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const int v = (int)d[rb][j][e];
+                        if (v != 0) {
+                            if (v < 0) {
+                                n_neg++;
+                            } else {
+                                if ((u64)v > maxv) maxv = (u64)v;
+                                if (v <= B) {
+                                    const u32 wb = laneWordByte + (u32)((j * PW + (e >> 1)) * CW) * 4u;
+                                    atomicAdd((u32*)(ldsHb + (u32)v * binRowBytes + wb),
+                                              (e & 1) ? 65536u : 1u);
+                                } else if ((long long)v < nbins) {
+                                    const long long k = (long long)chunk * E + e;
+                                    atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                } else {
+                                    n_over_cells++;
+                                }
+                                acc[j][e] = __dadd_rn(acc[j][e], __dmul_rn((double)v, w));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- flush the LDS histograms: non-zero counters only, 64-bit global atomics ----------------
+    for (int idx = BRW + tid; idx < (B + 1) * BRW; idx += BLOCK) {
+        const u32 word = ldsH[idx];
+        if (word == 0) continue;
+        const u32 v = (u32)idx / (u32)BRW;
+        const u32 wi = (u32)idx - v * (u32)BRW;
+        const u32 jp = wi / (u32)CW, cc = wi - jp * (u32)CW;
+        const u32 j = jp / PW, p = jp - j * PW;
+        const u32 chunk = MULTI ? cc : cc + 64u * j;
+        if (chunk >= (u32)C) continue;
+        const long long k0 = (long long)chunk * E + (E >= 2 ? 2 * p : 0);
+        const u32 lo = word & 0xffffu, hi = word >> 16;
+        if (lo) atomicAdd(&a.hist[k0 * nbins + v], (u64)lo);
+        if (hi) atomicAdd(&a.hist[(k0 + 1) * nbins + v], (u64)hi);
+    }
+    for (int t = tid; t < TB; t += BLOCK) {
+        const u32 cnt = ldsV[t];
+        if (cnt) atomicAdd(&a.histV[t], (u64)cnt);
+    }
+
+    // ---- mean accumulators: lanes -> LDS -> fixed-order sum over waves (and side-by-side rows) ----
+    double* ldsD = (double*)lds;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) ldsD[tid * E + e] = acc[j][e];
+        __syncthreads();
+        for (int t = tid; t < CW * E; t += BLOCK) {
+            const int cc = t / E, e = t - cc * E;
+            const int chunk = MULTI ? cc : cc + 64 * j;
+            if (chunk < C) {
+                double sum = 0.0;
+                for (int w = 0; w < W; ++w)
+                    for (int rr = 0; rr < R; ++rr)
+                        sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + e]);
+                a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
+            }
+        }
+    }
+
+    // ---- status ------------------------------------------------------------------------------
+    const u32 oc = dme_wave_sum_u32(n_over_cells), orow = dme_wave_sum_u32(n_over_rows);
+    const u32 ng = dme_wave_sum_u32(n_neg);
+    const u64 mv = dme_wave_max_u64(maxv), mt = dme_wave_max_u64(maxt);
+    if (lane == 0) {
+        if (oc) atomicAdd(&a.status[1], (u64)oc);
+        if (orow) atomicAdd(&a.status[2], (u64)orow);
+        if (ng) atomicAdd(&a.status[3], (u64)ng);
+        if (mv) atomicMax(&a.status[4], mv);
+        if (mt) atomicMax(&a.status[5], mt);
+        if (tid == 0) atomicAdd(&a.status[0], (u64)nrows);
+    }
+}
+
+// init_acc[k] += sum over workgroups (fixed order) of part[g][k]
+__global__ __launch_bounds__(256) void init_reduce_kernel(const double* part, long long G,
+                                                          long long K, double* init_acc) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (long long g = 0; g < G; ++g) s = __dadd_rn(s, part[g * K + k]);
+    init_acc[k] = __dadd_rn(init_acc[k], s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR rows.  One wave per row: lanes stride over the row's stored entries, the row total is a wave
+// reduction, every entry then adds 1 to hist[col][val] (64-bit global atomic; bag-of-words data
+// has K far beyond what LDS can privatise) and val*w to the per-workgroup... — the mean accumulator
+// is a global fp64 atomic here (K is too large for registers), so unlike the dense kernels its
+// last bits depend on arrival order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr, const int* colidx,
+                                                        const int* vals, long long N, long long K,
+                                                        u64* hist, long long nbins, u64* histV,
+                                                        long long tbins, double* init_acc,
+                                                        u64* status) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    u32 n_over_cells = 0, n_over_rows = 0, n_neg = 0;
+    u64 maxv = 0, maxt = 0, nrows = 0;
+    for (long long i = wave0; i < N; i += nwaves) {
+        const long long p0 = rowptr[i], p1 = rowptr[i + 1];
+        u64 s = 0;
+        for (long long p = p0 + lane; p < p1; p += 64) {
+            const int v = vals[p];
+            s += (u64)(v > 0 ? v : 0);
+        }
+        const u64 total = dme_wave_sum_u64(s);
+        nrows++;
+        if (lane == 0 && total > 0) {
+            if (total > maxt) maxt = total;
+            if ((long long)total < tbins) atomicAdd(&histV[total], 1ULL);
+            else n_over_rows++;
+        }
+        const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+        for (long long p = p0 + lane; p < p1; p += 64) {
+            const int v = vals[p];
+            const long long k = colidx[p];
+            if (v == 0) continue;
+            if (v < 0 || k < 0 || k >= K) { n_neg++; continue; }
+            if ((u64)v > maxv) maxv = (u64)v;
+            if ((long long)v < nbins) atomicAdd(&hist[k * nbins + v], 1ULL);
+            else n_over_cells++;
+            atomicAdd(&init_acc[k], __dmul_rn((double)v, w));
+        }
+    }
+    const u32 oc = dme_wave_sum_u32(n_over_cells), orow = dme_wave_sum_u32(n_over_rows);
+    const u32 ng = dme_wave_sum_u32(n_neg);
+    const u64 mv = dme_wave_max_u64(maxv), mt = dme_wave_max_u64(maxt);
+    if (lane == 0) {
+        if (oc) atomicAdd(&status[1], (u64)oc);
+        if (orow) atomicAdd(&status[2], (u64)orow);
+        if (ng) atomicAdd(&status[3], (u64)ng);
+        if (mv) atomicMax(&status[4], mv);
+        if (mt) atomicMax(&status[5], mt);
+        if (nrows) atomicAdd(&status[0], nrows);
+    }
+}
+
+constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
+constexpr int kMaxJ = 8;
+
+struct Plan {
+    int E, J, C, R, B, BRW, TB, block, lds_bytes, rows_per_wg;
+    long long grid;
+    bool multi;
+};
+
+int plan_dense(int elem_bytes, const void* X, long long N, long long K, long long ld,
+               long long nbins, long long tbins, Plan* pl) {
+    int E = 16 / elem_bytes;
+    const uintptr_t addr = (uintptr_t)X;
+    while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
+    if (addr % elem_bytes) return dme_set_error(DME_ERR_INVALID_ARG, "X is not element-aligned");
+    const long long C = K / E;
+    Plan p{};
+    p.E = E;
+    p.C = (int)C;
+    p.multi = C < 64;
+    if (p.multi) {
+        p.J = 1;
+        p.R = (int)(64 / C);
+    } else {
+        long long j = (C + 63) / 64;
+        int J = 1;
+        while (J < j) J <<= 1;
+        if (J > kMaxJ)
+            return dme_set_error(DME_ERR_UNSUPPORTED,
+                                 "dense stats: K=%lld with %d-element vectors needs %lld vectors per "
+                                 "lane (max %d); pad K / align rows to 16 bytes, or use the CSR entry",
+                                 K, E, j, kMaxJ);
+        p.J = J;
+        p.R = 1;
+    }
+    const int PW = E >= 2 ? E / 2 : 1;
+    const int CW = p.multi ? (int)C : 64;
+    p.BRW = p.J * PW * CW;
+    p.block = (p.J * E > 16) ? 512 : 1024;
+    long long TB = tbins < 2048 ? tbins : 2048;
+    long long avail = kLdsBudgetBytes / 4 - TB;
+    long long B = avail / p.BRW - 1;
+    if (B > nbins - 1) B = nbins - 1;
+    if (B > 65535) B = 65535;
+    if (B < 0) B = 0;
+    p.B = (int)B;
+    p.TB = (int)TB;
+    long long lds = (TB + (B + 1) * (long long)p.BRW) * 4;
+    const long long acc_bytes = (long long)p.block * E * 8;  // mean-accumulator exchange
+    if (lds < acc_bytes) lds = acc_bytes;
+    p.lds_bytes = (int)((lds + 15) & ~15LL);
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    // one workgroup per CU per round; a workgroup handles at most 65535 rows (16-bit LDS counters)
+    long long rounds = (N + (long long)cus * 65535 - 1) / ((long long)cus * 65535);
+    if (rounds < 1) rounds = 1;
+    long long grid = (long long)cus * rounds;
+    long long rpw = (N + grid - 1) / grid;
+    const long long min_rows = 64LL * p.R;
+    if (rpw < min_rows) rpw = min_rows;
+    grid = (N + rpw - 1) / rpw;
+    if (grid < 1) grid = 1;
+    p.rows_per_wg = (int)rpw;
+    p.grid = grid;
+    *pl = p;
+    return DME_OK;
+}
+
+template <typename T, int E, int J, bool MULTI>
+int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    auto kern = stats_dense_kernel<T, E, J, MULTI>;
+    // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB)
+    DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kLdsBudgetBytes + 4096));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(p.block), p.lds_bytes, s, a);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+template <typename T, int E>
+int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    if (p.multi) return launch_dense<T, E, 1, true>(a, p, s);
+    switch (p.J) {
+        case 1: return launch_dense<T, E, 1, false>(a, p, s);
+        case 2: return launch_dense<T, E, 2, false>(a, p, s);
+        case 4: return launch_dense<T, E, 4, false>(a, p, s);
+        case 8: return launch_dense<T, E, 8, false>(a, p, s);
+    }
+    return dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
+}
+
+template <typename T>
+int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
+                u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
+                long long workspace_bytes, void* stream) {
+    DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", N, K, ld);
+    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
+    DME_REQUIRE(hist && histV && init_acc && status, "null output pointer");
+    DME_REQUIRE(K * nbins < (1LL << 40), "hist too large");
+    if (N == 0) return DME_OK;
+    DME_REQUIRE(X != nullptr, "X is null");
+    Plan p;
+    int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, &p);
+    if (rc) return rc;
+    const long long need = p.grid * K * 8;
+    if (!workspace || workspace_bytes < need)
+        return dme_set_error(DME_ERR_WORKSPACE, "stats workspace: need %lld bytes, got %lld", need,
+                             workspace_bytes);
+    StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, status,
+                p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB};
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int EMAX = 16 / (int)sizeof(T);
+    switch (p.E) {
+        case 1: rc = dispatch_j<T, 1>(a, p, s); break;
+        case 2: rc = dispatch_j<T, 2>(a, p, s); break;
+        case 4: rc = dispatch_j<T, 4>(a, p, s); break;
+        case 8:
+            if constexpr (EMAX >= 8) rc = dispatch_j<T, 8>(a, p, s);
+            else rc = dme_set_error(DME_ERR_INTERNAL, "bad E");
+            break;
+        default: rc = dme_set_error(DME_ERR_INTERNAL, "bad E=%d", p.E);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s,
+                       (const double*)workspace, p.grid, K, init_acc);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    long long rounds = (N + (long long)cus * 65535 - 1) / ((long long)cus * 65535);
+    if (rounds < 1) rounds = 1;
+    return (int64_t)((long long)cus * rounds * K * 8 + 256);
+}
+
+extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,
+                                   uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
+                                   double* init_acc, uint64_t* status, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    return stats_dense<unsigned short>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
+                                       (u64*)status, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dme_stats_dense_i32(const int32_t* X, int64_t N, int64_t K, int64_t ld,
+                                   uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
+                                   double* init_acc, uint64_t* status, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    return stats_dense<int>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
+                            (u64*)status, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, const int32_t* vals,
+                                 int64_t N, int64_t K, uint64_t* hist, int64_t nbins,
+                                 uint64_t* histV, int64_t tbins, double* init_acc, uint64_t* status,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    DME_REQUIRE(N >= 0 && K >= 1, "bad shape N=%lld K=%lld", (long long)N, (long long)K);
+    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
+    DME_REQUIRE(hist && histV && init_acc && status, "null output pointer");
+    if (N == 0) return DME_OK;
+    DME_REQUIRE(rowptr && colidx && vals, "null CSR pointer");
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    long long waves = N < (long long)cus * 32 ? N : (long long)cus * 32;
+    long long grid = (waves + 3) / 4;
+    hipLaunchKernelGGL(stats_csr_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)rowptr, colidx, vals, (long long)N, (long long)K,
+                       (u64*)hist, (long long)nbins, (u64*)histV, (long long)tbins, init_acc,
+                       (u64*)status);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}

@@ -1,0 +1,404 @@
+"""Device-resident statistics and solver front-end (host side of the C ABI in include/dme_hip.h).
+
+torch is used for device buffers, streams and torch.distributed only; every computation on the
+hot path is a HIP kernel in libdme_hip.so.  There is no CPU fallback: without a GPU these classes
+raise.
+
+Reference mapping (DirichletEstimation/dirichletMultinomialEstimation.py = "DE/dme.py"):
+    DeviceStats.add_dense / add_csr   <- CompressedRowData.appendRow over all rows (DE/dme.py:113-123)
+                                         + the CLI mean accumulator (DE/fdp.py:87-89)
+    DeviceStats.finalize              <- the U/V lists those calls leave behind
+    DeviceUV.evaluate                 <- dirichLogProb / priorGradient / priorHessian* (:16-61)
+    DeviceUV.solve                    <- findDirichletPriors (:126-190)
+"""
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib
+
+EXIT_MESSAGES = {
+    1: "Converged with small gradient",    # DE/dme.py:146
+    2: "Converged with small learn rate",  # DE/dme.py:183
+    3: "Reached max iterations",           # DE/dme.py:189
+}
+
+
+def require_gpu(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("bayespy_amd needs an AMD GPU (MI355X, ROCm): no HIP device is visible "
+                           "and there is no CPU fallback")
+    _lib.lib()
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("bayespy_amd runs on the GPU only")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class DeviceUV:
+    """The reference's compressed statistics on the device: dense-padded fp64 U (K x ldU),
+    lenU[K], V, lenV — what every solver entry point consumes."""
+
+    def __init__(self, K, Uf, ldU, lenU, Vf, lenV, U=None, V=None):
+        self.K = int(K)
+        self.Uf, self.ldU, self.lenU = Uf, int(ldU), lenU
+        self.Vf, self.lenV = Vf, lenV
+        self.capV = int(Vf.numel())
+        self.Ui, self.Vi = U, V  # exact int64 copies when built by the scan
+        self.device = Uf.device
+        self._ws = None
+
+    # -- construction from host-side ragged lists (foreign data objects with .U/.V) ------------
+    @classmethod
+    def from_lists(cls, U, V, device=None):
+        device = require_gpu(device)
+        K = len(U)
+        ldU = max(1, max((len(u) for u in U), default=0))
+        host = np.zeros((K, ldU), dtype=np.float64)
+        lenU = np.zeros(K, dtype=np.int64)
+        for k, u in enumerate(U):
+            n = len(u)
+            lenU[k] = n
+            if n:
+                host[k, :n] = np.asarray(u, dtype=np.float64)
+        capV = max(1, len(V))
+        vhost = np.zeros(capV, dtype=np.float64)
+        if len(V):
+            vhost[:len(V)] = np.asarray(V, dtype=np.float64)
+        return cls(K, torch.from_numpy(host).to(device), ldU, torch.from_numpy(lenU).to(device),
+                   torch.from_numpy(vhost).to(device),
+                   torch.tensor([len(V)], dtype=torch.int64, device=device))
+
+    def workspace(self):
+        if self._ws is None:
+            nbytes = _lib.lib().dme_solver_workspace_bytes(self.K, self.ldU, self.capV)
+            self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    def to_lists(self):
+        """(U, V) as the reference holds them: ragged lists of ints."""
+        lenU = self.lenU.cpu().numpy()
+        lenV = int(self.lenV.cpu()[0])
+        if self.Ui is not None:
+            Uh = self.Ui.view(self.K, self.ldU).cpu().numpy()
+            Vh = self.Vi.cpu().numpy()
+            U = [[int(x) for x in Uh[k, :lenU[k]]] for k in range(self.K)]
+            V = [int(x) for x in Vh[:lenV]]
+        else:
+            Uh = self.Uf.view(self.K, self.ldU).cpu().numpy()
+            Vh = self.Vf.cpu().numpy()
+            U = [Uh[k, :lenU[k]].tolist() for k in range(self.K)]
+            V = Vh[:lenV].tolist()
+        return U, V
+
+    # -- one evaluation: loss, gradient, Hessian parts (DE/dme.py:16-61) -------------------------
+    def evaluate(self, alpha, hyperprior=0.0):
+        """Returns (logprob, hconst, grad[K], hdiag[K], gradSq) as host values."""
+        with torch.cuda.device(self.device):
+            a = torch.as_tensor(np.asarray(alpha, dtype=np.float64)).to(self.device)
+            if a.numel() != self.K:
+                raise ValueError(f"expected {self.K} alphas, got {a.numel()}")
+            scal = torch.empty(4, dtype=torch.float64, device=self.device)
+            grad = torch.empty(self.K, dtype=torch.float64, device=self.device)
+            hdiag = torch.empty(self.K, dtype=torch.float64, device=self.device)
+            ws, wsb = self.workspace()
+            _lib.check(_lib.lib().dme_eval(
+                _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                _ptr(self.lenV), self.K, _ptr(a), float(hyperprior), _ptr(scal), _ptr(grad),
+                _ptr(hdiag), ws, wsb, _stream()))
+            s = scal.cpu().numpy()
+            return float(s[0]), float(s[1]), grad.cpu().numpy(), hdiag.cpu().numpy(), float(s[3])
+
+    # -- the Newton loop (DE/dme.py:126-190) ----------------------------------------------------
+    def solve(self, init_alphas, iterations, hyperprior=0.0, trace_alphas=True):
+        """Runs findDirichletPriors on the device.  Returns a dict: alpha (np.float64[K]),
+        exit (1/2/3), n_iters, n_evals, final_loss, trace (n_iters x 4: loss, gradSq, branch,
+        learnRate), trace_alpha (n_iters x K or None)."""
+        iterations = int(iterations)
+        with torch.cuda.device(self.device):
+            if isinstance(init_alphas, torch.Tensor):
+                a = init_alphas.detach().to(device=self.device, dtype=torch.float64).clone()
+            else:
+                a = torch.as_tensor(np.array(init_alphas, dtype=np.float64)).to(self.device)
+            if a.numel() != self.K:
+                raise ValueError(f"expected {self.K} alphas, got {a.numel()}")
+            cap = max(iterations, 1)
+            trace = torch.zeros(cap * 4, dtype=torch.float64, device=self.device)
+            talpha = (torch.zeros(cap * self.K, dtype=torch.float64, device=self.device)
+                      if trace_alphas else None)
+            result = torch.zeros(8, dtype=torch.int64, device=self.device)
+            floss = torch.zeros(1, dtype=torch.float64, device=self.device)
+            ws, wsb = self.workspace()
+            _lib.check(_lib.lib().dme_solve(
+                _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(trace),
+                _ptr(talpha), cap, _ptr(result), _ptr(floss), ws, wsb, _stream()))
+            res = result.cpu().numpy()
+            n = int(res[1])
+            return {
+                "alpha": a.cpu().numpy(),
+                "alpha_device": a,
+                "exit": int(res[0]),
+                "n_iters": n,
+                "n_evals": int(res[2]),
+                "launches": int(res[4]),
+                "final_loss": float(floss.cpu()[0]),
+                "trace": trace.view(cap, 4)[:n].cpu().numpy(),
+                "trace_alpha": (talpha.view(cap, self.K)[:n].cpu().numpy()
+                                if talpha is not None else None),
+            }
+
+
+class DeviceStats:
+    """Value histograms of a count matrix, accumulated on the device.
+
+    hist[k][v] = #rows with x_ik == v, histV[t] = #rows with total t, init_acc[k] = the CLI's
+    mean accumulator.  Row chunks and row shards (GPUs) simply add, so `allreduce()` is one integer
+    sum; `finalize()` runs the reverse suffix scan that yields the reference's U/V."""
+
+    def __init__(self, K, max_count=1, max_total=1, device=None):
+        self.device = require_gpu(device)
+        self.K = int(K)
+        self.nbins = max(int(max_count), 1) + 1
+        self.tbins = max(int(max_total), 1) + 1
+        with torch.cuda.device(self.device):
+            self.hist = torch.zeros(self.K * self.nbins, dtype=torch.int64, device=self.device)
+            self.histV = torch.zeros(self.tbins, dtype=torch.int64, device=self.device)
+            self.init_acc = torch.zeros(self.K, dtype=torch.float64, device=self.device)
+            self.status = torch.zeros(8, dtype=torch.int64, device=self.device)
+        self._ws = None
+
+    # -- capacity -------------------------------------------------------------------------------
+    def reserve(self, max_count, max_total):
+        """Grow the histograms so that counts <= max_count and totals <= max_total fit."""
+        nb = max(self.nbins, int(max_count) + 1)
+        tb = max(self.tbins, int(max_total) + 1)
+        if nb != self.nbins:
+            new = torch.zeros(self.K, nb, dtype=torch.int64, device=self.device)
+            new[:, :self.nbins] = self.hist.view(self.K, self.nbins)
+            self.hist, self.nbins = new.view(-1), nb
+        if tb != self.tbins:
+            new = torch.zeros(tb, dtype=torch.int64, device=self.device)
+            new[:self.tbins] = self.histV
+            self.histV, self.tbins = new, tb
+
+    def _workspace(self, N):
+        need = _lib.lib().dme_stats_workspace_bytes(int(N), self.K) + 256
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws.data_ptr() + off, self._ws.numel() - off
+
+    # -- the statistics pass --------------------------------------------------------------------
+    def add_dense(self, X, max_count=None, max_total=None):
+        """Adds every row of X (device tensor, uint16 or int32, row-major N x K).  max_count /
+        max_total are upper bounds on a cell / a row total; when omitted they are measured with
+        one extra pass over X (torch), so pass them when known.  Asynchronous; data errors
+        (bounds exceeded, negative cells) surface in check()."""
+        if not isinstance(X, torch.Tensor):
+            raise TypeError("X must be a torch tensor on the GPU")
+        if X.device != self.device:
+            raise ValueError(f"X is on {X.device}, statistics on {self.device}")
+        if X.dim() != 2 or X.shape[1] != self.K:
+            raise ValueError(f"X must be N x {self.K}, got {tuple(X.shape)}")
+        if X.shape[0] == 0:
+            return self
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        if X.dtype in (torch.uint16, torch.int16):
+            fn = _lib.lib().dme_stats_dense_u16
+            as_signed = X.view(torch.int16) if X.dtype == torch.uint16 else X
+        elif X.dtype == torch.int32:
+            fn = _lib.lib().dme_stats_dense_i32
+            as_signed = X
+        else:
+            raise TypeError(f"unsupported dtype {X.dtype}: use uint16 or int32")
+        if max_count is None or max_total is None:
+            # bounds are measured, not guessed (an extra read of X; avoid by passing them)
+            wide = as_signed.to(torch.int64)
+            if X.dtype in (torch.uint16, torch.int16):
+                wide = wide & 0xFFFF
+            max_count = int(wide.max()) if max_count is None else max_count
+            max_total = int(wide.sum(dim=1).max()) if max_total is None else max_total
+        self.reserve(max_count, max_total)
+        with torch.cuda.device(self.device):
+            ws, wsb = self._workspace(X.shape[0])
+            rc = fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
+                    self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
+                    _ptr(self.status), ws, wsb, _stream())
+            if rc == _lib.ERR_UNSUPPORTED:
+                return self._add_dense_repacked(X, max_count, max_total)
+            _lib.check(rc)
+        return self
+
+    def _add_dense_repacked(self, X, max_count, max_total):
+        """Layouts the vector loads cannot take (odd row pitch / K with many columns): copy into
+        a 16-byte-aligned matrix whose K is padded with zero columns, run that, keep columns < K.
+        Costs one extra pass; only awkward layouts come here."""
+        per16 = 16 // X.element_size()
+        Kp = -(-self.K // per16) * per16
+        Xp = torch.zeros((X.shape[0], Kp), dtype=X.dtype, device=self.device)
+        Xp[:, :self.K] = X
+        tmp = DeviceStats(Kp, max_count, max_total, device=self.device)
+        with torch.cuda.device(self.device):
+            ws, wsb = tmp._workspace(X.shape[0])
+            fn = (_lib.lib().dme_stats_dense_i32 if X.dtype == torch.int32
+                  else _lib.lib().dme_stats_dense_u16)
+            _lib.check(fn(Xp.data_ptr(), Xp.shape[0], Kp, Kp, _ptr(tmp.hist), tmp.nbins,
+                          _ptr(tmp.histV), tmp.tbins, _ptr(tmp.init_acc), _ptr(tmp.status),
+                          ws, wsb, _stream()))
+        cut = DeviceStats(self.K, tmp.nbins - 1, tmp.tbins - 1, device=self.device)
+        cut.hist = tmp.hist.view(Kp, tmp.nbins)[:self.K].contiguous().view(-1)
+        cut.histV, cut.status = tmp.histV, tmp.status
+        cut.init_acc = tmp.init_acc[:self.K].contiguous()
+        return self.merge_(cut)
+
+    def add_csr(self, rowptr, colidx, vals, max_count=None, max_total=None):
+        """Adds CSR rows (rowptr int64[N+1], colidx int32[nnz], vals int32[nnz], all on device)."""
+        for t, dt, nm in ((rowptr, torch.int64, "rowptr"), (colidx, torch.int32, "colidx"),
+                          (vals, torch.int32, "vals")):
+            if t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                raise ValueError(f"{nm} must be a contiguous {dt} tensor on {self.device}")
+        N = rowptr.numel() - 1
+        if N <= 0:
+            return self
+        if colidx.numel() != vals.numel():
+            raise ValueError("colidx and vals differ in length")
+        if max_count is None:
+            max_count = int(vals.max()) if vals.numel() else 0
+        if max_total is None:
+            cs = torch.zeros(vals.numel() + 1, dtype=torch.int64, device=self.device)
+            cs[1:] = torch.cumsum(vals.to(torch.int64), 0)
+            max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
+        self.reserve(max_count, max_total)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().dme_stats_csr_i32(
+                _ptr(rowptr), _ptr(colidx), _ptr(vals), N, self.K, _ptr(self.hist), self.nbins,
+                _ptr(self.histV), self.tbins, _ptr(self.init_acc), _ptr(self.status), 0, 0,
+                _stream()))
+        return self
+
+    def check(self):
+        """Synchronises and raises if the pass met data it could not count."""
+        st = self.status.cpu().numpy()
+        if st[3]:
+            raise ValueError(f"{int(st[3])} negative counts (or column indices out of range)")
+        if st[1] or st[2]:
+            raise ValueError(
+                f"statistics incomplete: {int(st[1])} cells >= {self.nbins} and {int(st[2])} row "
+                f"totals >= {self.tbins} (largest seen: count {int(st[4])}, total {int(st[5])}); "
+                "max_count / max_total passed to add_* were too small")
+        return {"rows": int(st[0]), "max_count": int(st[4]), "max_total": int(st[5])}
+
+    @property
+    def rows(self):
+        return int(self.status[0].cpu())
+
+    # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
+    def allreduce(self, group=None):
+        """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs).  One MAX reduce
+        agrees the histogram extents, then one integer SUM over hist || histV || status and one
+        fp64 SUM over the K mean accumulators.  After it every rank holds the global statistics
+        and solves redundantly; there is no per-iteration communication."""
+        from .parallel import allreduce_stats_tensors
+        (self.hist, self.histV, self.status, self.init_acc, self.nbins,
+         self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
+                                               self.K, self.nbins, self.tbins, group)
+        return self
+
+    def merge_(self, other):
+        """In-place sum with another DeviceStats on the same device (logical shards)."""
+        if other.K != self.K:
+            raise ValueError("K differs")
+        self.reserve(other.nbins - 1, other.tbins - 1)
+        self.hist.view(self.K, self.nbins)[:, :other.nbins] += other.hist.view(other.K, other.nbins)
+        self.histV[:other.tbins] += other.histV
+        self.init_acc += other.init_acc
+        mx = torch.maximum(self.status[4:6], other.status[4:6])
+        self.status += other.status
+        self.status[4:6] = mx
+        return self
+
+    # -- scan -------------------------------------------------------------------------------------
+    def finalize(self):
+        """Reverse suffix scan -> DeviceUV (the reference's U/V, exact integers + fp64 copies)."""
+        K, dev = self.K, self.device
+        ldU = max(self.nbins - 1, 1)
+        capV = max(self.tbins - 1, 1)
+        with torch.cuda.device(dev):
+            U = torch.zeros(K * ldU, dtype=torch.int64, device=dev)
+            Uf = torch.zeros(K * ldU, dtype=torch.float64, device=dev)
+            lenU = torch.zeros(K, dtype=torch.int64, device=dev)
+            V = torch.zeros(capV, dtype=torch.int64, device=dev)
+            Vf = torch.zeros(capV, dtype=torch.float64, device=dev)
+            lenV = torch.zeros(1, dtype=torch.int64, device=dev)
+            _lib.check(_lib.lib().dme_suffix_scan(
+                _ptr(self.hist), K, self.nbins, _ptr(self.histV), self.tbins, _ptr(U), _ptr(Uf),
+                ldU, _ptr(lenU), _ptr(V), _ptr(Vf), _ptr(lenV), _stream()))
+        return DeviceUV(K, Uf, ldU, lenU, Vf, lenV, U=U, V=V)
+
+    def cli_init_alphas(self):
+        """DE/fdp.py:104-108 on the device: init_acc / (sum + 0.01) + 0.01."""
+        with torch.cuda.device(self.device):
+            a0 = torch.empty(self.K, dtype=torch.float64, device=self.device)
+            _lib.check(_lib.lib().dme_cli_init_alphas(_ptr(self.init_acc), self.K, _ptr(a0),
+                                                      _stream()))
+        return a0
+
+
+def predicted_step(hconst, hdiag, grad, alphas=None, device=None):
+    """getPredictedStep (alphas None) / getPredictedStepAlt on the device (DE/dme.py:67-80)."""
+    device = require_gpu(device)
+    with torch.cuda.device(device):
+        hd = torch.as_tensor(np.asarray(hdiag, dtype=np.float64)).to(device)
+        g = torch.as_tensor(np.asarray(grad, dtype=np.float64)).to(device)
+        K = g.numel()
+        if hd.numel() != K:
+            raise ValueError("hDiag and gradient differ in length")
+        step = torch.empty(K, dtype=torch.float64, device=device)
+        status = torch.zeros(1, dtype=torch.int64, device=device)
+        if alphas is None:
+            _lib.check(_lib.lib().dme_predicted_step(float(hconst), _ptr(hd), _ptr(g), K,
+                                                     _ptr(step), _ptr(status), _stream()))
+        else:
+            a = torch.as_tensor(np.asarray(alphas, dtype=np.float64)).to(device)
+            _lib.check(_lib.lib().dme_predicted_step_alt(float(hconst), _ptr(hd), _ptr(g), _ptr(a),
+                                                         K, _ptr(step), _ptr(status), _stream()))
+        _lib.check(int(status.cpu()[0]))
+        return step.cpu().numpy()
+
+
+def synth_dirmult(N, K, alpha, totals, seed, dtype=torch.uint16, row_offset=0, device=None,
+                  out=None):
+    """Synthetic DirichletMultinomial(totals[i], alpha) rows generated on the device
+    (dme_synth_dirmult).  totals: int32 device tensor [N].  Returns an N x K tensor."""
+    device = require_gpu(device)
+    with torch.cuda.device(device):
+        alpha = np.asarray(alpha, dtype=np.float64)
+        cdf = torch.from_numpy(np.cumsum(alpha)).to(device)
+        totals = totals.to(device=device, dtype=torch.int32).contiguous()
+        max_total = int(totals.max()) if N else 0
+        X = out if out is not None else torch.empty((N, K), dtype=dtype, device=device)
+        eb = X.element_size()
+        nb = _lib.lib().dme_synth_scratch_bytes(max_total)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().dme_synth_dirmult(
+            X.data_ptr(), eb, N, K, X.stride(0), _ptr(totals), max_total, _ptr(cdf), int(seed),
+            int(row_offset), _ptr(scratch), nb, _stream()))
+        torch.cuda.current_stream().synchronize()
+        del scratch
+    return X

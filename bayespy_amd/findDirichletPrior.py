@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Finding the optimal dirichlet prior from counts — GPU drop-in for the reference CLI.
+
+Same command line, stdin and stdout as DirichletEstimation/findDirichletPrior.py ("DE/fdp.py")
+of maxsklar/BayesPy, plus the NumPy port's -d/--delimiter (NumpyPort/findDirichletPrior.py:57):
+
+    cat test.csv | ./findDirichletPrior.py --sampleRate 1
+
+Rows are parsed on the host exactly as the reference does (csv.reader, int()), then handed to the
+GPU as one matrix: the statistics pass, the suffix scan, the CLI's initial-alpha formula
+(DE/fdp.py:87-89, 104-108) and the whole Newton loop run in HIP kernels.
+"""
+import os
+import sys
+
+if __package__ in (None, ""):  # executed as a script: make the package importable
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    __package__ = "bayespy_amd"
+
+import csv
+import logging
+import random
+import time
+from optparse import OptionParser
+
+import numpy as np
+
+from . import dirichletMultinomialEstimation as DME
+from . import samplingTools as Sample
+
+
+def main(argv=None, stdin=None, stdout=None):
+    stdin = sys.stdin if stdin is None else stdin
+    stdout = sys.stdout if stdout is None else stdout
+    startTime = time.time()
+    parser = OptionParser()
+    parser.add_option('-s', '--sampleRate', dest='sampleRate', default='1', help='If set to 1, sample every row; if set <1, each row is selected independently on this probability')
+    parser.add_option('-K', '--numCategories', dest='K', default='2', help='The number of (tab separated) categories that are being counted')
+    parser.add_option('-M', '--maxCountPerRow', dest='M', type=int, default=sys.maxsize, help='The maximum number of the count per row.  Setting this lower decreases the running time')
+    parser.add_option("-L", '--loglevel', action="store", dest="loglevel", default='DEBUG', help="don't print status messages to stdout. choose among (ERROR|WARNING|INFO|DEBUG)")
+    parser.add_option('-H', '--hyperPrior', dest='H', default='0', help='The hyperprior of the Dirichlet (number): a higher value indicates more bias towards tight dirichlets (very close to a single multinomial). Normally choose 0.')
+    parser.add_option('-i', '--iterations', dest='iterations', default='50', help='Stop at this number of iterations if the results have not converged.')
+    parser.add_option('-d', '--delimiter', dest='delimiter', default='\t', help='The delimited of your CSV file (default is tab)')
+
+    (options, args) = parser.parse_args(argv)
+
+    K = int(options.K)
+    iterations = int(options.iterations)
+    # Set the log level
+    log_level = options.loglevel
+    numeric_level = getattr(logging, log_level, None)
+    if not isinstance(numeric_level, int):
+        raise ValueError('Invalid log level: %s' % log_level)
+    logging.basicConfig(level=numeric_level)
+
+    logging.debug("K = " + str(K))
+
+    hyperprior = float(options.H)
+    logging.debug("Hyperprior (lambda) = " + str(hyperprior))
+
+    #####
+    # Load Data
+    #####
+    csv.field_size_limit(1000000000)
+    reader = csv.reader(stdin, delimiter=options.delimiter)
+    logging.debug("Loading data")
+
+    dataObj = DME.CompressedRowData(K)
+    sampleRate = float(options.sampleRate)
+
+    idx = 0
+    for row in reader:
+        idx += 1
+
+        if (random.random() < sampleRate):
+            data = list(map(int, row))
+            if (len(data) != K):
+                logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
+                logging.error("line %s: %s" % (idx, data))
+
+            while sum(data) > options.M: data[Sample.drawCategory(data)] -= 1
+
+            # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
+            dataObj.appendRow(data, 1)
+
+        if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
+
+    dataLoadTime = time.time()
+    logging.debug("loaded %s records into memory" % idx)
+    logging.debug("time to load memory: %s " % (dataLoadTime - startTime))
+
+    # initial priors: DE/fdp.py:104-108 on the device
+    stats = dataObj.deviceStats()
+    stats.check()
+    priors = stats.cli_init_alphas().cpu().numpy().tolist()
+
+    priors = DME.findDirichletPriors(dataObj, priors, iterations, hyperprior)
+
+    print("Final priors: " + str(priors), file=stdout)
+    logging.debug("Final average loss: %s" % DME.getTotalLoss(priors, dataObj, hyperprior))
+
+    totalTime = time.time() - dataLoadTime
+    logging.debug("Time to calculate: %s" % totalTime)
+    return priors
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * dme_hip.h — C ABI of libdme_hip.so, the MI355X (gfx950) implementation of the
+ * Dirichlet-multinomial MLE hot path of maxsklar/BayesPy.
+ *
+ * The reference has no FFI: its boundary for this path is the Python module
+ * DirichletEstimation/dirichletMultinomialEstimation.py ("DE/dme.py") called from
+ * DirichletEstimation/findDirichletPrior.py ("DE/fdp.py").  Each entry point below names the
+ * reference lines it replaces.  bayespy_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is a device pointer (hipMalloc / torch tensor data_ptr()),
+ *     owned by the caller; the library allocates nothing and keeps no state between calls
+ *     (dme_solve only: a few bytes of pinned host memory for its completion poll);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - return value: DME_OK or a DME_ERR_* code; the text is in dme_last_error() (thread-local);
+ *   - all launches are asynchronous on `stream` unless the entry says it synchronises;
+ *   - nothing throws across the ABI.
+ */
+#ifndef DME_HIP_H
+#define DME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DME_ABI_VERSION 1
+
+#define DME_OK 0
+#define DME_ERR_INVALID_ARG 1   /* bad shape / pointer / alignment                               */
+#define DME_ERR_HIP 2           /* a HIP runtime call failed                                     */
+#define DME_ERR_UNSUPPORTED 3   /* shape outside what the kernels are instantiated for           */
+#define DME_ERR_WORKSPACE 4     /* workspace too small (see *_workspace_bytes)                   */
+#define DME_ERR_ZERO_DIVISION 5 /* the reference would raise ZeroDivisionError (DE/dme.py:69-71) */
+#define DME_ERR_MATH_DOMAIN 6   /* the reference would raise ValueError (math.log of x <= 0)     */
+#define DME_ERR_INTERNAL 7
+
+int dme_abi_version(void);
+const char* dme_last_error(void);
+
+/* Number of compute units of the current device (used by callers to size workspaces). */
+int dme_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Statistics build.  Replaces CompressedRowData.appendRow (DE/dme.py:113-123) applied to every
+ * row, plus the CLI's mean accumulator (DE/fdp.py:87-89), in one pass over the count matrix.
+ *
+ * Output is the VALUE HISTOGRAM form of the statistics (all += so that row chunks / shards add):
+ *     hist [k*nbins + v] += #{rows i : x_ik == v}            v in [1, nbins)   (bin 0 unused)
+ *     histV[t]           += #{rows i : sum_k x_ik == t}      t in [1, tbins)   (bin 0 unused)
+ *     init_acc[k]        += sum_i x_ik / (1 + sum_k x_ik)    (fp64; DE/fdp.py:88-89)
+ * dme_suffix_scan turns hist/histV into the reference's U/V.  Integer results are exact.
+ *
+ * status[8] [dev] (uint64, += ; caller zeroes):
+ *     [0] rows processed        [1] cells with count >= nbins (NOT counted: result incomplete)
+ *     [2] rows with total >= tbins (NOT counted)              [3] negative cells (i32 only)
+ *     [4] max count seen        [5] max row total seen
+ * The caller must check status[1..3] == 0 (they are data errors, reported after the fact so
+ * that the pass stays asynchronous).
+ *
+ * X is row-major, `ld` elements between rows (ld >= K).  Dense kernels need
+ * ceil(K / E / 64) <= 8 where E is the largest power of two <= 16/sizeof(elem) that divides K, ld
+ * and the element offset of X (K <= 4096 for 16-byte-aligned uint16 rows); otherwise
+ * DME_ERR_UNSUPPORTED (use the CSR entry).
+ * workspace: dme_stats_workspace_bytes(N, K) bytes [dev], 256-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);
+
+int dme_stats_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                        uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,
+                        int64_t tbins, double* init_acc /*[dev]*/, uint64_t* status /*[dev]*/,
+                        void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
+
+int dme_stats_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                        uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,
+                        int64_t tbins, double* init_acc /*[dev]*/, uint64_t* status /*[dev]*/,
+                        void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
+
+/* CSR rows (rowptr int64[N+1], colidx int32[nnz], vals int32[nnz]); same outputs.  Entries with
+ * value 0 are legal and ignored, as a zero count is in DE/dme.py:117. */
+int dme_stats_csr_i32(const int64_t* rowptr /*[dev]*/, const int32_t* colidx /*[dev]*/,
+                      const int32_t* vals /*[dev]*/, int64_t N, int64_t K, uint64_t* hist,
+                      int64_t nbins, uint64_t* histV, int64_t tbins, double* init_acc,
+                      uint64_t* status, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reverse suffix scan: value histograms -> the reference's compressed statistics
+ * (closed form of DE/dme.py:116-123):
+ *     U[k*ldU + n] = sum_{v > n} hist[k*nbins + v]   = #{i : x_ik > n},   n in [0, nbins-1)
+ *     V[n]         = sum_{t > n} histV[t]            = #{i : sum_k x_ik > n}
+ *     lenU[k] = len(U[k]) = largest v with hist[k][v] > 0 (0 if none);  lenV[0] likewise.
+ * U/V are written as int64 (exact) and, when Uf/Vf are non-NULL, also as fp64 for the solver.
+ * Entries at n >= lenU[k] are written as 0.  ldU >= nbins-1; V/Vf hold tbins-1 entries.
+ * ------------------------------------------------------------------------------------------- */
+int dme_suffix_scan(const uint64_t* hist /*[dev]*/, int64_t K, int64_t nbins,
+                    const uint64_t* histV /*[dev]*/, int64_t tbins, int64_t* U /*[dev]*/,
+                    double* Uf /*[dev] or NULL*/, int64_t ldU, int64_t* lenU /*[dev] [K]*/,
+                    int64_t* V /*[dev]*/, double* Vf /*[dev] or NULL*/,
+                    int64_t* lenV /*[dev] [1]*/, void* stream);
+
+/* DE/fdp.py:104-108: alpha0[k] = init_acc[k] / (sum(init_acc) + 0.01) + 0.01 */
+int dme_cli_init_alphas(const double* init_acc /*[dev]*/, int64_t K, double* alpha0 /*[dev]*/,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Solver.  U is dense-padded fp64: U[k][n] = Uf[k*ldU + n] for n < lenU[k]; V = Vf[0..lenV).
+ * lenU [K] and lenV [1] are device arrays (as written by dme_suffix_scan).
+ * workspace: dme_solver_workspace_bytes(K, ldU, capV) bytes [dev], 256-byte aligned, where
+ * capV >= lenV is the allocated length of Vf.
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_solver_workspace_bytes(int64_t K, int64_t ldU, int64_t capV);
+
+/* One evaluation at `alpha` [dev][K]: backs dirichLogProb (DE/dme.py:16-29), priorGradient
+ * (:32-48), priorHessianConst (:52-53) and priorHessianDiag (:55-61) one-to-one.
+ *     out_scalars[0] = log-probability (:29)      out_scalars[1] = hConst (:53)
+ *     out_scalars[2] = sum(alpha)                  out_scalars[3] = sum_k grad_k^2 (:104)
+ *     out_grad[K], out_hdiag[K]                    (either may be NULL)
+ * Asynchronous. */
+int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
+             const int64_t* lenV, int64_t K, const double* alpha, double hyperprior,
+             double* out_scalars /*[dev][4]*/, double* out_grad /*[dev][K]*/,
+             double* out_hdiag /*[dev][K]*/, void* workspace, int64_t workspace_bytes,
+             void* stream);
+
+/* getPredictedStep (DE/dme.py:67-72) and getPredictedStepAlt (:76-80) on device vectors.
+ * status [dev][1] int64: 0 ok, DME_ERR_ZERO_DIVISION if the reference would divide by zero. */
+int dme_predicted_step(double hconst, const double* hdiag /*[dev]*/, const double* grad /*[dev]*/,
+                       int64_t K, double* step /*[dev]*/, int64_t* status /*[dev]*/, void* stream);
+int dme_predicted_step_alt(double hconst, const double* hdiag, const double* grad,
+                           const double* alphas, int64_t K, double* step, int64_t* status,
+                           void* stream);
+
+/* findDirichletPriors (DE/dme.py:126-190): the whole Newton loop on the device — loss, gradient,
+ * Hessian, Sherman-Morrison step, strict-< acceptance (:160), log-space trial (:165-172), x0.9
+ * step halving (:175-180), exits A/B/C (:145-147, :182-184, :189-190).
+ *   alpha [dev][K]: in = initAlphas, out = returned priors.
+ *   trace [dev][trace_cap][4] or NULL: per iteration {currentLoss, gradientSize, branch, learnRate}
+ *       as logged at DE/dme.py:143 (branch: how the PREVIOUS iterate was reached: 0 init,
+ *       1 Newton, 2 log-space, 3 gradient/halving).
+ *   trace_alpha [dev][trace_cap][K] or NULL: the priors logged at :143.
+ *   result [dev][8] int64: [0] exit reason (1 = small gradient, 2 = small learn rate,
+ *       3 = max iterations), [1] iterations, [2] loss evaluations, [3] error
+ *       (0 / DME_ERR_ZERO_DIVISION / DME_ERR_MATH_DOMAIN), [4] kernel launches used.
+ *   final_loss [dev][1] or NULL: getTotalLoss at the returned priors.
+ * The host only re-enqueues batches of (evaluate, step) launches and polls a done flag once per
+ * batch; every decision is taken on the device.  SYNCHRONISES `stream` before returning.
+ * Returns DME_ERR_ZERO_DIVISION / DME_ERR_MATH_DOMAIN where the reference raises. */
+int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
+              const int64_t* lenV, int64_t K, double* alpha, int64_t iterations,
+              double hyperprior, double* trace, double* trace_alpha, int64_t trace_cap,
+              int64_t* result, double* final_loss, void* workspace, int64_t workspace_bytes,
+              void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Synthetic count rows for benchmarks and tests (no reference counterpart: the reference's
+ * generators are host-side samplers, DE/samplingTools.py:41-67).  Row i draws
+ * x_i ~ DirichletMultinomial(totals[i], alpha) by the Polya-urn scheme (draw j copies a uniformly
+ * chosen earlier draw with probability (j)/(A + j), else draws from alpha/A), counter-based RNG
+ * keyed on (seed, row_offset + i).  cdf [dev][K] = inclusive prefix sums of alpha (fp64).
+ * scratch: dme_synth_scratch_bytes(max_total) bytes [dev].  elem_bytes: 2 (uint16) or 4 (int32).
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_synth_scratch_bytes(int64_t max_total);
+int dme_synth_dirmult(void* X /*[dev]*/, int elem_bytes, int64_t N, int64_t K, int64_t ld,
+                      const int32_t* totals /*[dev][N]*/, int64_t max_total,
+                      const double* cdf /*[dev][K]*/, uint64_t seed, int64_t row_offset,
+                      void* scratch, int64_t scratch_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DME_HIP_H */

@@ -1,0 +1,130 @@
+"""The drop-in Python surface on the GPU: module functions with the reference's signatures,
+CompressedRowData.appendRow, and the findDirichletPrior CLI (stdin TSV -> stdout line)."""
+import io
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _rows_text(fx, delim="\t"):
+    return "".join(delim.join(str(int(v)) for v in r) + "\n" for r in fx["X"])
+
+
+def test_append_row_protocol():
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    fx = load_golden("test_csv")
+    obj = DME.CompressedRowData(2)
+    for r in fx["rows"]:
+        obj.appendRow(r, 1)
+    assert obj.K == 2
+    assert obj.U == fx["U"] and obj.V == fx["V"]
+    # appending after a read keeps accumulating
+    obj.appendRow([3, 1], 1)
+    U2 = [list(u) for u in fx["U"]]
+    for j in range(3):
+        U2[0][j] += 1
+    U2[1][0] += 1
+    assert obj.U == U2
+
+
+def test_module_functions_match_reference_values():
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    fx = load_golden("test_csv")
+    obj = DME.CompressedRowData(2)
+    obj.appendMatrix(fx["X"])
+    g = fx["funcs"][0]["DE"]
+    a, hp = g["alpha"], g["hyperprior"]
+    np.testing.assert_allclose(DME.dirichLogProb(a, obj, hp), g["logprob"], rtol=1e-12)
+    np.testing.assert_allclose(DME.dirichletLogProb(a, obj, hp), g["logprob"], rtol=1e-12)
+    np.testing.assert_allclose(DME.getTotalLoss(a, obj, hp), g["loss"], rtol=1e-12)
+    np.testing.assert_allclose(DME.priorGradient(a, obj, hp), g["grad"], rtol=1e-9)
+    np.testing.assert_allclose(DME.priorHessianConst(a, obj), g["hconst"], rtol=1e-12)
+    np.testing.assert_allclose(DME.priorHessianDiag(a, obj), g["hdiag"], rtol=1e-12)
+    np.testing.assert_allclose(DME.getPredictedStep(g["hconst"], g["hdiag"], g["grad"]), g["step"],
+                               rtol=1e-11)
+    np.testing.assert_allclose(DME.getPredictedStepAlt(g["hconst"], g["hdiag"], g["grad"], a),
+                               g["stepAlt"], rtol=1e-11)
+    np.testing.assert_allclose(DME.predictStepUsingHessian(g["grad"], a, obj), g["step"], rtol=1e-9)
+    np.testing.assert_allclose(DME.predictStepLogSpace(g["grad"], a, obj), g["stepAlt"], rtol=1e-9)
+    assert DME.testTrialPriors([0.0, 1.0], obj) == float("inf")
+    np.testing.assert_allclose(DME.testTrialPriors(a, obj, hp), g["loss"], rtol=1e-12)
+    assert DME.sqVectorSize(g["grad"]) == g["gradSq"]
+    with pytest.raises(ValueError):
+        DME.dirichLogProb([-1.0, 1.0], obj, 0)
+
+
+def test_find_priors_accepts_foreign_data_objects():
+    """Other callers hand over their own object with .K/.U/.V (DR/dirichletRegression.py:137-139)."""
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+
+    class Foreign:
+        pass
+
+    fx = load_golden("one_doublesided")
+    f = Foreign()
+    f.K, f.U, f.V = fx["K"], fx["U"], fx["V"]
+    s = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "ones"][0]
+    out = DME.findDirichletPriors(f, [1.0] * 2, 50)
+    np.testing.assert_allclose(out, s["final"], rtol=1e-9)
+
+
+def test_zero_column_raises_like_reference():
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    fx = load_golden("zero_column")
+    obj = DME.CompressedRowData(3)
+    for r in fx["rows"]:
+        obj.appendRow(r, 1)
+    with pytest.raises(ZeroDivisionError):
+        DME.findDirichletPriors(obj, fx["alpha0_cli"], 50)
+
+
+def test_row_length_errors():
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    obj = DME.CompressedRowData(3)
+    with pytest.raises(IndexError):
+        obj.appendRow([1, 2], 1)
+    # over-long row: first K entries feed U, the whole row feeds V (DE/dme.py:116-123)
+    obj.appendRow([1, 0, 2, 4], 1)
+    obj.appendRow([0, 1, 0], 1)
+    assert obj.U == [[1], [1], [1, 1]]
+    assert obj.V == [2, 1, 1, 1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("name,K", [("test_csv", 2), ("test_txt", 2), ("one_doublesided", 2),
+                                    ("dirmult_k50", 50)])
+def test_cli_stdout_matches_reference(name, K, caplog):
+    """C1: `cat test.csv | findDirichletPrior.py` prints `Final priors: [...]` (DE/fdp.py:112)."""
+    from bayespy_amd import findDirichletPrior as cli
+    fx = load_golden(name)
+    ref = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "cli"
+           and s["hyperprior"] == 0][0]
+    out = io.StringIO()
+    with caplog.at_level(logging.DEBUG):
+        cli.main(["-K", str(K)], stdin=io.StringIO(_rows_text(fx)), stdout=out)
+    line = out.getvalue().strip()
+    assert line.startswith("Final priors: [") and line.endswith("]")
+    got = [float(x) for x in line[len("Final priors: ["):-1].split(",")]
+    np.testing.assert_allclose(got, ref["final"], rtol=1e-9)
+    msgs = [r.getMessage() for r in caplog.records]
+    assert sum(m.startswith("Iteration: ") for m in msgs) == ref["n_iters"]
+    assert "Converged with small gradient" in msgs
+    assert any(m.startswith("Final average loss: ") for m in msgs)
+
+
+def test_cli_delimiter_and_hyperprior():
+    from bayespy_amd import findDirichletPrior as cli
+    fx = load_golden("test_csv")
+    ref = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "cli"
+           and s["hyperprior"] == -0.1][0]
+    out = io.StringIO()
+    cli.main(["-K", "2", "-d", ",", "-H", "-0.1", "-L", "ERROR"],
+             stdin=io.StringIO(_rows_text(fx, ",")), stdout=out)
+    got = [float(x) for x in out.getvalue().strip()[len("Final priors: ["):-1].split(",")]
+    np.testing.assert_allclose(got, ref["final"], rtol=1e-9)

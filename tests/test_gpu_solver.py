@@ -1,0 +1,131 @@
+"""GPU parity of the solver (dme_eval, dme_predicted_step*, dme_solve) against golden vectors
+produced by the reference (DE variant) and against the CPU oracle.
+
+Tolerances (BASELINE.json north_star): alphas within 1e-9 relative, log-likelihood / loss within
+1e-12 relative.  The device sums in a different (parallel, compensated) order than the
+reference's sequential loops, so bit equality is not expected for floating point."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+RTOL_ALPHA = 1e-9
+RTOL_LOSS = 1e-12
+
+
+def _uv(fx):
+    from bayespy_amd import device
+    return device.DeviceUV.from_lists(fx["U"], fx["V"])
+
+
+@pytest.mark.parametrize("name", [c for c in GOLDEN_CASES])
+def test_function_level(name):
+    from bayespy_amd import device
+    fx = load_golden(name)
+    uv = _uv(fx)
+    for rec in fx["funcs"]:
+        g = rec["DE"]
+        lp, hc, grad, hd, gsq = uv.evaluate(g["alpha"], g["hyperprior"])
+        np.testing.assert_allclose(lp, g["logprob"], rtol=RTOL_LOSS)
+        np.testing.assert_allclose(hc, g["hconst"], rtol=1e-12)
+        np.testing.assert_allclose(hd, g["hdiag"], rtol=1e-12)
+        # the gradient is a difference of two large sums: absolute tolerance scaled by them
+        scale = max(1.0, np.max(np.abs(g["hdiag"])) ** 0.5, abs(g["hconst"]) ** 0.5)
+        tsub = np.max(np.abs(g["grad"])) + 1.0
+        np.testing.assert_allclose(grad, g["grad"], rtol=1e-9, atol=1e-12 * tsub * scale)
+        if g["step"] is None:
+            with pytest.raises(ZeroDivisionError):
+                device.predicted_step(g["hconst"], g["hdiag"], g["grad"])
+        else:
+            np.testing.assert_allclose(device.predicted_step(g["hconst"], g["hdiag"], g["grad"]),
+                                       g["step"], rtol=1e-11, atol=1e-18)
+            np.testing.assert_allclose(
+                device.predicted_step(g["hconst"], g["hdiag"], g["grad"], alphas=g["alpha"]),
+                g["stepAlt"], rtol=1e-11, atol=1e-18)
+
+
+def _solve_cases():
+    out = []
+    for name in GOLDEN_CASES:
+        fx = load_golden(name)
+        for i, s in enumerate(fx["solves"]):
+            if s["variant"] == "DE":
+                out.append((name, i))
+    return out
+
+
+# Branch histories that the reference itself does not reproduce between its own DE and NumPy
+# variants (the x0.9 halving loop ends on a loss difference below one ulp): only the returned
+# alphas / exit are compared there, not the evaluation count.
+NOISE_LIMITED = {("dirmult_k50", "cli", 0.01), ("dirmult_k50", "ones", 0.01)}
+# A trajectory that diverges (alpha grows to 2.5e6 in 50 iterations, exit C): the reference's own
+# DE and NumPy variants differ there by 4.2e-12 in alpha and 4.3e-12 in the loss, so the loss
+# tolerance is 1e-10 for it (alphas still meet 1e-9).
+DIVERGING = {("test_csv", "fifty", 0.25)}
+
+
+@pytest.mark.parametrize("name,idx", _solve_cases())
+def test_solve_matches_reference(name, idx):
+    fx = load_golden(name)
+    s = fx["solves"][idx]
+    uv = _uv(fx)
+    if "raises" in s:
+        with pytest.raises(ZeroDivisionError):
+            uv.solve(s["init"], s["iterations"], s["hyperprior"])
+        return
+    out = uv.solve(s["init"], s["iterations"], s["hyperprior"])
+    key = (name, s["init_name"], s["hyperprior"])
+    exits = {"A": 1, "B": 2, "C": 3}
+    assert out["exit"] == exits[s["exit"]], key
+    np.testing.assert_allclose(out["alpha"], s["final"], rtol=RTOL_ALPHA, err_msg=str(key))
+    rl = 1e-10 if key in DIVERGING else RTOL_LOSS
+    np.testing.assert_allclose(out["final_loss"], s["final_loss"], rtol=rl)
+    assert out["n_iters"] == s["n_iters"], key
+    if key not in NOISE_LIMITED:
+        assert out["n_evals"] == s["n_evals"], key
+    tl = [t["loss"] for t in s["trace"]]
+    np.testing.assert_allclose(out["trace"][:, 0], tl, rtol=rl)
+    tg = np.array([t["gradSq"] for t in s["trace"]])
+    np.testing.assert_allclose(out["trace"][:, 1], tg, rtol=1e-6, atol=1e-9)
+    ta = np.array([t["priors"] for t in s["trace"]])
+    np.testing.assert_allclose(out["trace_alpha"], ta, rtol=RTOL_ALPHA)
+
+
+def test_solve_vs_oracle_on_gpu_built_stats(oracle):
+    """End to end on the device: statistics kernel -> scan -> init alphas -> solver, against the
+    oracle run on the same matrix."""
+    from bayespy_amd import device
+    for name in ("dirmult_k1000", "dirmult_k50", "heavy_k20", "flipcoins_1500"):
+        fx = load_golden(name)
+        X = fx["X"]
+        st = device.DeviceStats(fx["K"])
+        st.add_dense(torch.from_numpy(np.ascontiguousarray(X.astype(np.int32))).cuda())
+        st.check()
+        uv = st.finalize()
+        a0 = st.cli_init_alphas()
+        out = uv.solve(a0, 50, 0.0)
+        ref_st = oracle.append_rows(X.astype(np.int32))
+        ref = oracle.find_priors(ref_st, ref_st.cli_init_alphas(), 50, 0.0)
+        np.testing.assert_allclose(out["alpha"], ref["alpha"], rtol=RTOL_ALPHA)
+        assert out["n_iters"] == ref["n_iters"] and out["n_evals"] == ref["n_evals"]
+        np.testing.assert_allclose(out["final_loss"],
+                                   oracle.total_loss(ref["alpha"], ref_st, 0.0), rtol=RTOL_LOSS)
+
+
+def test_nonpositive_init_raises():
+    fx = load_golden("test_csv")
+    uv = _uv(fx)
+    with pytest.raises(ValueError):
+        uv.solve([0.0, 1.0], 50, 0.0)
+
+
+def test_zero_iterations_returns_init():
+    fx = load_golden("test_csv")
+    uv = _uv(fx)
+    out = uv.solve([0.5, 0.25], 0, 0.0)
+    assert out["exit"] == 3 and out["n_iters"] == 0
+    assert out["alpha"].tolist() == [0.5, 0.25]

@@ -1,0 +1,220 @@
+"""GPU parity of the statistics build (dme_stats_dense_*, dme_stats_csr_i32, dme_suffix_scan)
+against the CPU oracle and the reference-generated golden fixtures.  Integer results are
+bit-exact; the fp64 mean accumulator differs from the reference only by summation order
+(tolerance 1e-12 relative, stated per assert)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev():
+    from bayespy_amd import device
+    return device
+
+
+def _to_dev(X, dtype):
+    if dtype == "u16":
+        return torch.from_numpy(np.ascontiguousarray(X.astype(np.uint16))).cuda()
+    return torch.from_numpy(np.ascontiguousarray(X.astype(np.int32))).cuda()
+
+
+def _build(X, dtype, **kw):
+    dev = _dev()
+    st = dev.DeviceStats(X.shape[1])
+    st.add_dense(_to_dev(X, dtype), **kw)
+    info = st.check()
+    return st, st.finalize(), info
+
+
+def _assert_uv_equal(uv, st_oracle):
+    U, V = uv.to_lists()
+    assert U == [list(map(int, u)) for u in st_oracle.U]
+    assert V == list(map(int, st_oracle.V))
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("dtype", ["i32", "u16"])
+def test_golden_stats_bit_exact(name, dtype):
+    fx = load_golden(name)
+    X = fx["X"]
+    if dtype == "u16" and X.max() > 65535:
+        pytest.skip("does not fit uint16")
+    st, uv, info = _build(X, dtype)
+    U, V = uv.to_lists()
+    assert U == fx["U"]
+    assert V == fx["V"]
+    assert info["rows"] == fx["N"]
+    assert info["max_count"] == int(X.max())
+    assert info["max_total"] == int(X.astype(np.int64).sum(axis=1).max())
+    # DE/fdp.py:87-89 accumulator: same products, different summation order -> 1e-12 relative
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), fx["init_acc"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(st.cli_init_alphas().cpu().numpy(), fx["alpha0_cli"], rtol=1e-12)
+
+
+SHAPES = [
+    # (N, K, max value, density)
+    (1, 1, 5, 1.0), (7, 1, 3, 0.5), (64, 2, 60, 0.9), (65, 3, 9, 0.7), (129, 5, 300, 0.6),
+    (1000, 7, 20, 0.3), (333, 8, 70000, 0.5), (257, 16, 12, 0.2), (500, 20, 100, 0.3),
+    (100, 63, 4, 0.1), (100, 64, 4, 0.1), (100, 65, 4, 0.1), (300, 100, 50, 0.1),
+    (200, 128, 1000, 0.05), (200, 129, 9, 0.05), (150, 250, 30, 0.1), (90, 512, 7, 0.1),
+    (120, 1000, 400, 0.07), (60, 1024, 3, 0.1), (40, 2048, 90, 0.02), (30, 4096, 5, 0.01),
+    (4500, 1000, 120, 0.05),
+]
+
+
+@pytest.mark.parametrize("N,K,vmax,density", SHAPES)
+@pytest.mark.parametrize("dtype", ["i32", "u16"])
+def test_random_shapes_vs_oracle(oracle, N, K, vmax, density, dtype):
+    if dtype == "u16" and vmax > 65535:
+        vmax = 65535
+    if dtype == "i32" and K > 2048:
+        pytest.skip("beyond the dense int32 kernel's K range")
+    rng = np.random.default_rng(N * 1000 + K)
+    X = rng.integers(1, vmax + 1, size=(N, K)) * (rng.random((N, K)) < density)
+    # a few large values to exercise the global-atomic path beside the LDS bins
+    X[rng.integers(0, N), rng.integers(0, K)] = vmax
+    ref = oracle.append_rows(X.astype(np.uint16) if dtype == "u16" else X.astype(np.int32))
+    st, uv, info = _build(X, dtype)
+    _assert_uv_equal(uv, ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
+
+
+def test_padded_rows_and_offsets(oracle):
+    """ld > K and a base pointer that is only element-aligned (narrower vector loads)."""
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    for K, ld, off in [(1000, 1008, 0), (1000, 1003, 0), (100, 100, 1), (20, 24, 2), (50, 64, 3)]:
+        N = 300
+        big = rng.integers(0, 40, size=(N, ld)) * (rng.random((N, ld)) < 0.2)
+        for dtype, npdt in (("u16", np.uint16), ("i32", np.int32)):
+            flat = torch.zeros(N * ld + 8, dtype=torch.int32 if dtype == "i32" else torch.uint16,
+                               device="cuda")
+            host = torch.from_numpy(big.astype(npdt).reshape(-1))
+            flat[off:off + N * ld] = host.cuda()
+            view = flat[off:off + N * ld].view(N, ld)[:, :K]
+            st = dev.DeviceStats(K)
+            st.add_dense(view, max_count=40, max_total=int(big[:, :K].sum(axis=1).max()))
+            st.check()
+            ref = oracle.append_rows(big[:, :K].astype(npdt))
+            _assert_uv_equal(st.finalize(), ref)
+            np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12)
+
+
+def test_empty_and_zero_rows(oracle):
+    dev = _dev()
+    st = dev.DeviceStats(4)
+    st.add_dense(torch.zeros((0, 4), dtype=torch.int32, device="cuda"))
+    st.add_dense(torch.zeros((10, 4), dtype=torch.int32, device="cuda"))
+    info = st.check()
+    assert info["rows"] == 10
+    U, V = st.finalize().to_lists()
+    assert U == [[], [], [], []] and V == []
+    assert st.init_acc.cpu().tolist() == [0.0] * 4
+
+
+def test_bounds_and_negative_are_reported():
+    dev = _dev()
+    X = torch.tensor([[1, 2], [300, 4]], dtype=torch.int32, device="cuda")
+    st = dev.DeviceStats(2)
+    st.add_dense(X, max_count=10, max_total=1000)
+    with pytest.raises(ValueError, match="incomplete"):
+        st.check()
+    st = dev.DeviceStats(2)
+    st.add_dense(X, max_count=300, max_total=5)
+    with pytest.raises(ValueError, match="incomplete"):
+        st.check()
+    st = dev.DeviceStats(2)
+    st.add_dense(torch.tensor([[1, -2]], dtype=torch.int32, device="cuda"), max_count=5, max_total=5)
+    with pytest.raises(ValueError, match="negative"):
+        st.check()
+
+
+def test_chunks_and_logical_shards_add_exactly(oracle):
+    """P logical row shards summed == the unsharded build, integer-exact, and the
+    same after accumulating chunk by chunk into one object."""
+    dev = _dev()
+    fx = load_golden("dirmult_k1000")
+    X = fx["X"]
+    from bayespy_amd.parallel import shard_rows
+    whole, uv_whole, _ = _build(X, "u16")
+    for P in (2, 3, 8):
+        acc = dev.DeviceStats(X.shape[1])
+        chunked = dev.DeviceStats(X.shape[1])
+        for r in range(P):
+            lo, hi = shard_rows(X.shape[0], r, P)
+            part = dev.DeviceStats(X.shape[1])
+            part.add_dense(_to_dev(X[lo:hi], "u16"))
+            acc.merge_(part)
+            chunked.add_dense(_to_dev(X[lo:hi], "u16"))
+        for st in (acc, chunked):
+            st.check()
+            U, V = st.finalize().to_lists()
+            assert U == fx["U"] and V == fx["V"]
+            np.testing.assert_allclose(st.init_acc.cpu().numpy(), whole.init_acc.cpu().numpy(),
+                                       rtol=1e-13)
+
+
+def test_reproducible_bits():
+    """Same input, same launch shape -> bit-identical fp64 accumulators (fixed summation order)."""
+    fx = load_golden("dirmult_k1000")
+    a, _, _ = _build(fx["X"], "u16")
+    b, _, _ = _build(fx["X"], "u16")
+    assert torch.equal(a.init_acc, b.init_acc)
+    assert torch.equal(a.hist, b.hist)
+
+
+def test_csr_matches_dense(oracle):
+    dev = _dev()
+    for name in ("dirmult_k50", "dirmult_k1000", "heavy_k20"):
+        fx = load_golden(name)
+        X = fx["X"].astype(np.int32)
+        nz = X != 0
+        rowptr = np.concatenate([[0], np.cumsum(nz.sum(axis=1))]).astype(np.int64)
+        colidx = np.nonzero(nz)[1].astype(np.int32)
+        vals = X[nz].astype(np.int32)
+        st = dev.DeviceStats(fx["K"])
+        st.add_csr(torch.from_numpy(rowptr).cuda(), torch.from_numpy(colidx).cuda(),
+                   torch.from_numpy(vals).cuda())
+        st.check()
+        U, V = st.finalize().to_lists()
+        assert U == fx["U"] and V == fx["V"]
+        np.testing.assert_allclose(st.init_acc.cpu().numpy(), fx["init_acc"], rtol=1e-12)
+
+
+def test_large_synthetic_properties():
+    """Size-independent checks at a size the oracle cannot reach (2M x 1000 uint16 = 4 GB):
+    sum_n U[k][n] = column sum, sum_n V[n] = grand total, V[0] = #non-empty rows,
+    U non-increasing, and two half-passes add up to the full pass."""
+    dev = _dev()
+    K, N = 1000, 2_000_000
+    rng = np.random.default_rng(0)
+    alpha = 0.01 + rng.gamma(2.0, 0.05, size=K)
+    totals = torch.randint(1, 501, (N,), dtype=torch.int32, device="cuda",
+                           generator=torch.Generator(device="cuda").manual_seed(1))
+    X = dev.synth_dirmult(N, K, alpha, totals, seed=20260003)
+    rowsum = X.view(torch.int16).to(torch.int32).bitwise_and(0xFFFF).sum(dim=1)
+    assert torch.equal(rowsum, totals)  # the generator itself: every row has its total
+    st = dev.DeviceStats(K)
+    st.add_dense(X, max_count=500, max_total=500)
+    info = st.check()
+    assert info["rows"] == N
+    uv = st.finalize()
+    U = uv.Ui.view(K, uv.ldU)
+    colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
+    for lo in range(0, N, 250_000):
+        colsum += X[lo:lo + 250_000].view(torch.int16).to(torch.int64).bitwise_and(0xFFFF).sum(dim=0)
+    assert torch.equal(U.sum(dim=1), colsum)
+    assert int(uv.Vi.sum()) == int(totals.to(torch.int64).sum())
+    assert int(uv.Vi[0]) == N
+    assert bool((U[:, 1:] <= U[:, :-1]).all())
+    half = dev.DeviceStats(K)
+    half.add_dense(X[:N // 2], max_count=500, max_total=500)
+    half.add_dense(X[N // 2:], max_count=500, max_total=500)
+    half.check()
+    assert torch.equal(half.hist, st.hist) and torch.equal(half.histV, st.histV)
+    np.testing.assert_allclose(half.init_acc.cpu().numpy(), st.init_acc.cpu().numpy(), rtol=1e-12)
