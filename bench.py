@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+metric : count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows), whole job
+workload: configs[2] = "K=1000 synthetic Dirichlet-multinomial, 10M rows, row totals 1-500"
+          (SURVEY 8d C3): uint16 dense rows resident in HBM, alpha_true = 0.01 + Gamma(2, 0.05)
+          (numpy seed 0), n_i ~ UniformInt[1, 500], x_i ~ DirichletMultinomial(n_i, alpha_true),
+          generated on the device (dme_synth_dirmult, seed 20260003).
+step    : one full pass of the hot path over the resident matrix:
+          statistics kernel -> [RCCL all-reduce of the integer histograms when N > 1] -> suffix
+          scan -> CLI initial alphas -> on-device Newton loop to convergence -> status check.
+scaling : weak — every rank holds its own 10M-row shard; value = all rows / max-over-ranks time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--dtype u16|i32]
+  (N > 1: launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL)
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the statistics
+launch; `cpu_baseline` times the CPU oracle (oracle/, a C port of the reference loops) on a bounded
+row sample on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU")
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--max-total", type=int, default=500)
+    ap.add_argument("--dtype", choices=["u16", "i32"], default="u16")
+    ap.add_argument("--iterations", type=int, default=50)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="check size-independent properties of the statistics after the run")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from bayespy_amd import device as dev
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    K, N, M = args.k, args.rows, args.max_total
+    tdtype = torch.uint16 if args.dtype == "u16" else torch.int32
+    esize = 2 if args.dtype == "u16" else 4
+
+    # ---- synthetic workload, generated on the device, not timed --------------
+    rng = np.random.default_rng(0)
+    alpha_true = 0.01 + rng.gamma(2.0, 0.05, size=K)
+    t0 = time.time()
+    gen = torch.Generator(device=device).manual_seed(20260003 + rank)
+    totals = torch.randint(1, M + 1, (N,), dtype=torch.int32, device=device, generator=gen)
+    X = dev.synth_dirmult(N, K, alpha_true, totals, seed=20260003, dtype=tdtype,
+                          row_offset=rank * N, device=device)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def one_step(timers=None):
+        st = dev.DeviceStats(K, M, M, device=device)
+        if timers is not None:
+            e0, e1 = ev(), ev()
+            e0.record()
+        st.add_dense(X, max_count=M, max_total=M)
+        if timers is not None:
+            e1.record()
+        st.allreduce()
+        uv = st.finalize()
+        a0 = st.cli_init_alphas()
+        out = uv.solve(a0, args.iterations, 0.0, trace_alphas=False)
+        info = st.check()
+        if timers is not None:
+            timers.append((e0, e1))
+        return st, uv, out, info
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timers = []
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        st, uv, out, info = one_step(timers)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+
+    ms_per_step = elapsed / args.steps * 1e3
+    stats_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))
+    total_rows = N * world
+    value = total_rows / (elapsed / args.steps)
+    assert info["rows"] == total_rows, (info, total_rows)
+
+    algo_bytes = N * K * esize  # the count matrix read exactly once (per GPU)
+    achieved = algo_bytes / (stats_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"stats_dense_{args.dtype}_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows)",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": ("K=%d synthetic Dirichlet-multinomial, %d rows per GPU, row totals 1-%d, "
+                         "%s dense (BASELINE configs[2])" % (K, N, M, "uint16" if esize == 2 else "int32")),
+            "K": K, "rows_per_gpu": N, "rows_total": total_rows, "max_row_total": M,
+            "input_dtype": args.dtype, "parallelism": "rows sharded x%d, replicated solve" % world,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "stats_dense_kernel", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+            "avg_launch_ms": stats_ms,
+        },
+        "phases_ms": {"stats": stats_ms, "rest (reduce+scan+init+solve+check)": ms_per_step - stats_ms},
+        "solver": {"iterations": out["n_iters"], "loss_evals": out["n_evals"], "exit": out["exit"],
+                   "launches": out["launches"], "final_loss": out["final_loss"]},
+        "gen_seconds": t_gen,
+    }
+
+    if args.verify and rank == 0:
+        U = uv.Ui.view(K, uv.ldU)
+        assert bool((U[:, 1:] <= U[:, :-1]).all())
+        assert int(uv.Vi[0]) == total_rows  # every row has total >= 1
+        if world == 1:
+            assert int(uv.Vi.sum()) == int(totals.to(torch.int64).sum())
+        line["verified"] = True
+
+    # ---- CPU baseline: the oracle (C port of the reference loops) on a bounded sample ------------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        ns = min(args.cpu_sample_rows, N)
+        Xh = X[:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = oracle.append_rows(Xh, capU=M, capV=M)
+        t_stats_cpu = time.perf_counter() - t0
+        # the solver's cost does not depend on N: time it on the full-size statistics
+        Ufull, Vfull = uv.to_lists()
+        full = oracle.stats_from_lists(Ufull, Vfull)
+        a0 = st.cli_init_alphas().cpu().numpy()
+        t0 = time.perf_counter()
+        sol = oracle.find_priors(full, a0, args.iterations, 0.0)
+        t_solve_cpu = time.perf_counter() - t0
+        cpu_total = t_stats_cpu * (N / ns) + t_solve_cpu
+        line["cpu_baseline"] = {
+            "value": N / cpu_total, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": ("oracle/dme_oracle.c (single-threaded C port of appendRow + mean accumulator) "
+                       "timed on the first %d rows: %.2f s, scaled linearly to %d rows; plus the "
+                       "oracle solver on the full-size U/V: %.3f s (%d iterations, %d loss evals)"
+                       % (ns, t_stats_cpu, N, t_solve_cpu, sol["n_iters"], sol["n_evals"])),
+            "host_cpus": os.cpu_count(),
+        }
+        rel = float(np.max(np.abs(out["alpha"] - sol["alpha"]) / np.abs(sol["alpha"])))
+        line["cpu_baseline"]["gpu_vs_oracle_max_rel_alpha_err"] = rel
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
