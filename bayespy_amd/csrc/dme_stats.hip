@@ -33,7 +33,9 @@ struct StatsArgs {
     long long nbins;
     u64* histV;
     long long tbins;
-    double* part;  // [gridDim.x][K] per-workgroup mean accumulators
+    double* part;    // [gridDim.x][K] per-workgroup mean accumulators
+    u32* hist_part;  // [gridDim.x][part_words] raw LDS histogram images, one per workgroup
+    long long part_words;
     u64* status;
     int rows_per_wg;
     int C;    // vectors (chunks) per row = K / E
@@ -41,6 +43,7 @@ struct StatsArgs {
     int B;    // LDS-privatised count bins 1..B (row 0 of the LDS histogram is the sink)
     int BRW;  // 32-bit words per LDS bin row
     int TB;   // LDS-privatised row-total bins [0, TB)
+    int TBpad;  // TB rounded up to a multiple of 4 words: offset of the count histogram in LDS
 };
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -97,8 +100,8 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     const int CW = MULTI ? C : 64;
     const int B = a.B, BRW = a.BRW, TB = a.TB;
     u32* ldsV = lds;
-    u32* ldsH = lds + TB;
-    const int nwords = TB + (B + 1) * BRW;
+    u32* ldsH = lds + a.TBpad;
+    const int nwords = (int)a.part_words;  // TB + (B+1)*BRW rounded up to a multiple of 4
     for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
     __syncthreads();
 
@@ -255,24 +258,14 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     }
     __syncthreads();
 
-    // ---- flush the LDS histograms: non-zero counters only, 64-bit global atomics ----------------
-    for (int idx = BRW + tid; idx < (B + 1) * BRW; idx += BLOCK) {
-        const u32 word = ldsH[idx];
-        if (word == 0) continue;
-        const u32 v = (u32)idx / (u32)BRW;
-        const u32 wi = (u32)idx - v * (u32)BRW;
-        const u32 jp = wi / (u32)CW, cc = wi - jp * (u32)CW;
-        const u32 j = jp / PW, p = jp - j * PW;
-        const u32 chunk = MULTI ? cc : cc + 64u * j;
-        if (chunk >= (u32)C) continue;
-        const long long k0 = (long long)chunk * E + (E >= 2 ? 2 * p : 0);
-        const u32 lo = word & 0xffffu, hi = word >> 16;
-        if (lo) atomicAdd(&a.hist[k0 * nbins + v], (u64)lo);
-        if (hi) atomicAdd(&a.hist[(k0 + 1) * nbins + v], (u64)hi);
-    }
-    for (int t = tid; t < TB; t += BLOCK) {
-        const u32 cnt = ldsV[t];
-        if (cnt) atomicAdd(&a.histV[t], (u64)cnt);
+    // ---- dump the LDS histogram image as it stands (coalesced 16-byte stores); hist_reduce_kernel
+    //      sums the images of all workgroups and decodes the layout.  (Flushing with global atomics
+    //      instead cost ~0.5 ms at K=1000: 18M scattered 8-byte atomics, profiles/r1_notes.md.)
+    {
+        u32x4* dst = (u32x4*)(a.hist_part + (long long)blockIdx.x * a.part_words);
+        const u32x4* src = (const u32x4*)lds;
+        const int n4 = (int)(a.part_words >> 2);
+        for (int i = tid; i < n4; i += BLOCK) dst[i] = src[i];
     }
 
     // ---- mean accumulators: lanes -> LDS -> fixed-order sum over waves (and side-by-side rows) ----
@@ -310,14 +303,71 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     }
 }
 
-// init_acc[k] += sum over workgroups (fixed order) of part[g][k]
+// init_acc[k] += sum over workgroups of part[g][k], in a fixed order: 4 interleaved slices of g
+// per column (threadIdx.y), combined 0+1+2+3 through LDS.
 __global__ __launch_bounds__(256) void init_reduce_kernel(const double* part, long long G,
                                                           long long K, double* init_acc) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ double sh[4][64];
+    const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
     double s = 0.0;
-    for (long long g = 0; g < G; ++g) s = __dadd_rn(s, part[g * K + k]);
-    init_acc[k] = __dadd_rn(init_acc[k], s);
+    if (k < K)
+        for (long long g = threadIdx.y; g < G; g += 4) s = __dadd_rn(s, part[g * K + k]);
+    sh[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && k < K) {
+        double t = __dadd_rn(__dadd_rn(sh[0][threadIdx.x], sh[1][threadIdx.x]),
+                             __dadd_rn(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+        init_acc[k] = __dadd_rn(init_acc[k], t);
+    }
+}
+
+// Sums the LDS histogram images of all workgroups and adds them into hist / histV.  One thread
+// column per image word (two packed 16-bit counters), 4 interleaved slices of workgroups per word.
+// Every (k, v) bin belongs to exactly one word, so the final += needs no atomics.
+struct ReduceArgs {
+    const u32* hist_part;
+    long long part_words, G;
+    u64* hist;
+    long long nbins;
+    u64* histV;
+    long long K;
+    int C, B, BRW, TB, TBpad, CW, PW, E, multi;
+};
+
+__global__ __launch_bounds__(256) void hist_reduce_kernel(ReduceArgs a) {
+    __shared__ u64 shlo[4][64], shhi[4][64];
+    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;  // word index in the image
+    const long long used = a.TBpad + (long long)(a.B + 1) * a.BRW;
+    u64 lo = 0, hi = 0;
+    if (idx < used)
+        for (long long g = threadIdx.y; g < a.G; g += 4) {
+            const u32 w = a.hist_part[g * a.part_words + idx];
+            lo += w & 0xffffu;
+            hi += w >> 16;
+        }
+    shlo[threadIdx.y][threadIdx.x] = lo;
+    shhi[threadIdx.y][threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.y != 0 || idx >= used) return;
+    lo = shlo[0][threadIdx.x] + shlo[1][threadIdx.x] + shlo[2][threadIdx.x] + shlo[3][threadIdx.x];
+    hi = shhi[0][threadIdx.x] + shhi[1][threadIdx.x] + shhi[2][threadIdx.x] + shhi[3][threadIdx.x];
+    if (idx < a.TBpad) {  // row-total bins: plain 32-bit counters
+        const u64 cnt = lo + (hi << 16);
+        if (cnt && idx < a.TB) a.histV[idx] += cnt;
+        return;
+    }
+    if ((lo | hi) == 0) return;
+    const u32 h = (u32)(idx - a.TBpad);
+    const u32 v = h / (u32)a.BRW;
+    if (v == 0) return;  // sink row
+    const u32 wi = h - v * (u32)a.BRW;
+    const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
+    const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
+    const u32 chunk = a.multi ? cc : cc + 64u * j;
+    if (chunk >= (u32)a.C) return;
+    const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
+    if (lo) a.hist[k0 * a.nbins + v] += lo;
+    if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -380,8 +430,8 @@ constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workg
 constexpr int kMaxJ = 8;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, block, lds_bytes, rows_per_wg;
-    long long grid;
+    int E, J, C, R, B, BRW, TB, TBpad, block, lds_bytes, rows_per_wg;
+    long long grid, part_words;
     bool multi;
 };
 
@@ -416,14 +466,17 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.BRW = p.J * PW * CW;
     p.block = (p.J * E > 16) ? 512 : 1024;
     long long TB = tbins < 2048 ? tbins : 2048;
-    long long avail = kLdsBudgetBytes / 4 - TB;
+    const long long TBpad = (TB + 3) & ~3LL;
+    long long avail = kLdsBudgetBytes / 4 - TBpad - 4;
     long long B = avail / p.BRW - 1;
     if (B > nbins - 1) B = nbins - 1;
     if (B > 65535) B = 65535;
     if (B < 0) B = 0;
     p.B = (int)B;
     p.TB = (int)TB;
-    long long lds = (TB + (B + 1) * (long long)p.BRW) * 4;
+    p.TBpad = (int)TBpad;
+    p.part_words = (TBpad + (B + 1) * (long long)p.BRW + 3) & ~3LL;
+    long long lds = p.part_words * 4;
     const long long acc_bytes = (long long)p.block * E * 8;  // mean-accumulator exchange
     if (lds < acc_bytes) lds = acc_bytes;
     p.lds_bytes = (int)((lds + 15) & ~15LL);
@@ -480,12 +533,15 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     Plan p;
     int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, &p);
     if (rc) return rc;
-    const long long need = p.grid * K * 8;
+    const long long init_bytes = (p.grid * K * 8 + 255) & ~255LL;
+    const long long need = init_bytes + p.grid * p.part_words * 4;
     if (!workspace || workspace_bytes < need)
         return dme_set_error(DME_ERR_WORKSPACE, "stats workspace: need %lld bytes, got %lld", need,
                              workspace_bytes);
-    StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, status,
-                p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB};
+    DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
+    u32* hist_part = (u32*)((char*)workspace + init_bytes);
+    StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     switch (p.E) {
@@ -499,7 +555,12 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
         default: rc = dme_set_error(DME_ERR_INTERNAL, "bad E=%d", p.E);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s,
+    const int PW = p.E >= 2 ? p.E / 2 : 1;
+    ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, K,
+                  p.C, p.B, p.BRW, p.TB, p.TBpad, p.multi ? p.C : 64, PW, p.E, p.multi ? 1 : 0};
+    const long long used = p.TBpad + (long long)(p.B + 1) * p.BRW;
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, 4), 0, s, ra);
+    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, 4), 0, s,
                        (const double*)workspace, p.grid, K, init_acc);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
@@ -512,7 +573,8 @@ extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
     if (cus <= 0) cus = 256;
     long long rounds = (N + (long long)cus * 65535 - 1) / ((long long)cus * 65535);
     if (rounds < 1) rounds = 1;
-    return (int64_t)((long long)cus * rounds * K * 8 + 256);
+    // per workgroup: K fp64 mean accumulators + one raw LDS histogram image
+    return (int64_t)((long long)cus * rounds * (K * 8 + kLdsBudgetBytes + 64) + 1024);
 }
 
 extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,
