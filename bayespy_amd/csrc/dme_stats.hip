@@ -20,6 +20,8 @@
 //     added to a sink row that is never flushed, so the hot loop has no per-element branch;
 //   * counts > B (rare) and row totals >= TB go straight to 64-bit global atomics;
 //   * at the end the workgroup flushes its non-zero LDS counters with 64-bit global atomics.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "dme_common.h"
@@ -43,8 +45,19 @@ struct StatsArgs {
     int B;    // LDS-privatised count bins 1..B (row 0 of the LDS histogram is the sink)
     int BRW;  // 32-bit words per LDS bin row
     int TB;   // LDS-privatised row-total bins [0, TB)
-    int TBpad;  // TB rounded up to a multiple of 4 words: offset of the count histogram in LDS
+    int TBpad;  // TB rounded up to a multiple of 4 words
+    int WT;     // LDS table of row weights 1/(1+n) for n in [0, WT), 2 words each, at word TBpad
+    int hoff;   // word offset of the count histogram in LDS = TBpad + 2*WT
+    int debug;  // unused (ablation is compile-time: DME_ABLATE below)
 };
+
+// Compile-time ablation switches for timing experiments (never set in the shipped build):
+// -DDME_ABLATE=<bits>: 1 no LDS count atomics, 2 no mean accumulators, 4 no large-count path,
+// 8 no row-total histogram.
+#ifndef DME_ABLATE
+#define DME_ABLATE 0
+#endif
+#define DBG(bit) ((DME_ABLATE) & (bit))
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
@@ -65,6 +78,22 @@ __device__ __forceinline__ void load_chunk(const void* p, u32 (&d)[ND]) {
     }
 }
 
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
+    u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(x, y));
+}
+
+// acc + x*w for the CLI's mean accumulator (DE/fdp.py:89 `priors[i] += data[i] * weightForMean`).
+// One fused multiply-add: the product is not rounded before the add (the reference rounds it), a
+// difference below the summation-order difference that already separates the two.
+__device__ __forceinline__ double mean_add(double acc, double x, double w) {
+#ifdef DME_NO_FMA
+    return __dadd_rn(acc, __dmul_rn(x, w));
+#else
+    return __fma_rn(x, w, acc);
+#endif
+}
+
 __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
     u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
     return __builtin_bit_cast(u32, __builtin_elementwise_max(x, y));
@@ -73,7 +102,7 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
 template <int J, int E>
 struct StatsCfg {
     static constexpr int BLOCK = (J * E > 16) ? 512 : 1024;
-    static constexpr int RB = (J <= 2) ? 4 : (J == 4 ? 2 : 1);  // row groups in flight per wave
+    static constexpr int RB = (J <= 2) ? 2 : 1;  // row groups per register buffer (two buffers)
 };
 
 // T: element type (unsigned short | int).  E: elements per vector load.  J: vectors per lane and
@@ -100,9 +129,15 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     const int CW = MULTI ? C : 64;
     const int B = a.B, BRW = a.BRW, TB = a.TB;
     u32* ldsV = lds;
-    u32* ldsH = lds + a.TBpad;
+    u32* ldsH = lds + a.hoff;
+    const double* ldsW = (const double*)(lds + a.TBpad);
+    const int WT = a.WT;
     const int nwords = (int)a.part_words;  // TB + (B+1)*BRW rounded up to a multiple of 4
     for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
+    __syncthreads();
+    // weightForMean = 1.0 / (1.0 + sumData) (DE/fdp.py:88), tabulated once per workgroup
+    for (int n = tid; n < WT; n += BLOCK)
+        ((double*)(lds + a.TBpad))[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
     __syncthreads();
 
     double acc[J][E];
@@ -111,7 +146,9 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[j][e] = 0.0;
     u32 n_over_cells = 0, n_over_rows = 0, n_neg = 0;
-    u64 maxv = 0, maxt = 0;
+    u64 maxv = 0, maxt = 0;  // only the rare global-atomic paths update these; the maxima of the
+                             // LDS-privatised bins are taken by hist_reduce_kernel
+    const u32 Bpk = (u32)a.B | ((u32)a.B << 16);
 
     const long long row0 = (long long)blockIdx.x * a.rows_per_wg;
     const long long row1 = min(a.N, row0 + (long long)a.rows_per_wg);
@@ -124,43 +161,48 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     const T* Xp = (const T*)a.X;
     const long long nbins = a.nbins, tbins = a.tbins;
 
-    for (long long g0 = wave; g0 < ngroups; g0 += (long long)W * RB) {
+    struct Buf {
         u32 d[RB][J][ND];
-        bool ok[RB];
-        long long rowi[RB];
+    };
+    const long long S = (long long)W * RB;  // row groups a workgroup retires per loop step
+
+    // issue the loads of RB row groups starting at group g0 (nothing is waited for here)
+    auto load_buf = [&](Buf& b, long long g0) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const long long g = g0 + (long long)rb * W;
-            rowi[rb] = row0 + g * R + r;
-            ok[rb] = (g < ngroups) && lane_has_row && (rowi[rb] < row1);
+            const long long rowi = row0 + g * R + r;
+            const bool ok = (g < ngroups) && lane_has_row && (rowi < row1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int chunk = c + 64 * j;
-                if (ok[rb] && chunk < C) {
-                    load_chunk<BYTES, ND>(Xp + rowi[rb] * a.ld + (long long)chunk * E, d[rb][j]);
+                if (ok && chunk < C) {
+                    load_chunk<BYTES, ND>(Xp + rowi * a.ld + (long long)chunk * E, b.d[rb][j]);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) d[rb][j][q] = 0;
+                    for (int q = 0; q < ND; ++q) b.d[rb][j][q] = 0;
                 }
             }
         }
+    };
+
+    auto process_buf = [&](Buf& b, long long g0) {
+        // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
+        SumT tot[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if (g0 + (long long)rb * W >= ngroups) break;  // wave-uniform
-            // ---- row total ---------------------------------------------------------------
             SumT s = 0;
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
                 for (int q = 0; q < ND; ++q) {
                     if constexpr (IS16) {
-                        s = __builtin_amdgcn_sad_u16(d[rb][j][q], 0u, s);
+                        s = __builtin_amdgcn_sad_u16(b.d[rb][j][q], 0u, s);
                     } else {
-                        const int v = (int)d[rb][j][q];
+                        const int v = (int)b.d[rb][j][q];
                         s += (SumT)(v > 0 ? v : 0);
                     }
                 }
-            SumT total;
             if constexpr (MULTI) {
                 SumT incl = s;
 #pragma unroll
@@ -169,90 +211,135 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                     if (c >= dd) incl += up;
                 }
                 int last = r * C + C - 1;
-                total = __shfl(incl, last > 63 ? 63 : last);
+                tot[rb] = __shfl(incl, last > 63 ? 63 : last);
             } else {
-                if constexpr (IS16) total = dme_wave_sum_u32(s);
-                else total = dme_wave_sum_u64(s);
+                if constexpr (IS16) tot[rb] = dme_wave_sum_u32(s);
+                else tot[rb] = dme_wave_sum_u64(s);
             }
-            // ---- row-total histogram (one lane per row) -------------------------------------
-            if (ok[rb] && c == 0 && total > 0) {
-                if ((u64)total > maxt) maxt = total;
-                if ((u64)total < (u64)TB) atomicAdd(&ldsV[(u32)total], 1u);
-                else if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
-                else n_over_rows++;
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const long long g = g0 + (long long)rb * W;
+            if (g >= ngroups) break;  // wave-uniform
+            const SumT total = tot[rb];
+            double w;
+            if constexpr (MULTI) {
+                // ---- row-total histogram: the first lane of every row ----------------------
+                const long long rowi = row0 + g * R + r;
+                if (lane_has_row && rowi < row1 && c == 0 && total > 0 && !DBG(8)) {
+                    if ((u64)total < (u64)TB) {
+                        atomicAdd(&ldsV[(u32)total], 1u);
+                    } else {
+                        if ((u64)total > maxt) maxt = total;
+                        if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
+                        else n_over_rows++;
+                    }
+                }
+                if ((u64)total < (u64)WT) w = ldsW[(u32)total];
+                else w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+            } else {
+                // ---- row-total histogram: `total` is wave-uniform, so these are scalar branches --
+                if ((u64)total < (u64)TB) {
+                    if (lane == 0 && total > 0 && !DBG(8)) atomicAdd(&ldsV[(u32)total], 1u);
+                } else if (!DBG(8)) {
+                    if ((u64)total > maxt) maxt = total;
+                    if (lane == 0) {
+                        if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
+                        else n_over_rows++;
+                    }
+                }
+                if ((u64)total < (u64)WT) w = ldsW[(u32)total];
+                else w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
             }
-            // weightForMean = 1.0 / (1.0 + sumData)            (DE/fdp.py:88)
-            const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
             // ---- cells --------------------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int chunk = c + 64 * j;
                 if constexpr (IS16) {
-                    // rare path first: any count > B in this vector?  (packed 16-bit max)
-                    u32 m = d[rb][j][0];
+                    // rare path first: any count > B in this vector?  packed 16-bit max over the
+                    // vector, then min(m, B|B) != m  <=>  some half exceeds B
+                    u32 m = b.d[rb][j][0];
 #pragma unroll
-                    for (int q = 1; q < ND; ++q) m = pk_max_u16(m, d[rb][j][q]);
-                    const u32 mlo = m & 0xffffu, mhi = (E >= 2) ? (m >> 16) : 0u;
-                    const u32 mx = mlo > mhi ? mlo : mhi;
-                    if (mx > (u32)B) {
-                        if ((u64)mx > maxv) maxv = mx;
+                    for (int q = 1; q < ND; ++q) m = pk_max_u16(m, b.d[rb][j][q]);
+                    if (__builtin_expect(pk_min_u16(m, Bpk) != m, 0) && !DBG(4)) {
 #pragma unroll
                         for (int q = 0; q < ND; ++q)
 #pragma unroll
                             for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
-                                const u32 v = h ? (d[rb][j][q] >> 16) : (d[rb][j][q] & 0xffffu);
+                                const u32 v = h ? (b.d[rb][j][q] >> 16) : (b.d[rb][j][q] & 0xffffu);
                                 if (v > (u32)B) {
                                     const long long k = (long long)chunk * E + 2 * q + h;
+                                    if ((u64)v > maxv) maxv = v;
                                     if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
                                     else n_over_cells++;
-                                    acc[j][2 * q + h] =
-                                        __dadd_rn(acc[j][2 * q + h], __dmul_rn((double)v, w));
-                                    d[rb][j][q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
+                                    acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, w);
+                                    b.d[rb][j][q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
                                 }
                             }
-                    } else if ((u64)mx > maxv) {
-                        maxv = mx;
                     }
 #pragma unroll
                     for (int q = 0; q < ND; ++q) {
-                        const u32 dw = d[rb][j][q];
-                        if (dw != 0) {
+                        const u32 dw = b.d[rb][j][q];
+                        if (__builtin_expect(dw != 0, 1)) {  // some lane of the wave almost always is
                             const u32 lo = dw & 0xffffu;
                             const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
-                            atomicAdd((u32*)(ldsHb + lo * binRowBytes + wb), 1u);
-                            acc[j][2 * q] = __dadd_rn(acc[j][2 * q], __dmul_rn((double)lo, w));
+                            if (!DBG(1)) atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb)), 1u);
+                            if (!DBG(2)) acc[j][2 * q] = mean_add(acc[j][2 * q], (double)lo, w);
                             if constexpr (E >= 2) {
                                 const u32 hi = dw >> 16;
-                                atomicAdd((u32*)(ldsHb + hi * binRowBytes + wb), 65536u);
-                                acc[j][2 * q + 1] =
-                                    __dadd_rn(acc[j][2 * q + 1], __dmul_rn((double)hi, w));
+                                if (!DBG(1))
+                                    atomicAdd((u32*)(ldsHb + (__umul24(hi, binRowBytes) + wb)), 65536u);
+                                if (!DBG(2))
+                                    acc[j][2 * q + 1] = mean_add(acc[j][2 * q + 1], (double)hi, w);
                             }
                         }
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
-                        const int v = (int)d[rb][j][e];
+                        const int v = (int)b.d[rb][j][e];
                         if (v != 0) {
                             if (v < 0) {
                                 n_neg++;
                             } else {
-                                if ((u64)v > maxv) maxv = (u64)v;
                                 if (v <= B) {
                                     const u32 wb = laneWordByte + (u32)((j * PW + (e >> 1)) * CW) * 4u;
-                                    atomicAdd((u32*)(ldsHb + (u32)v * binRowBytes + wb),
+                                    atomicAdd((u32*)(ldsHb + (__umul24((u32)v, binRowBytes) + wb)),
                                               (e & 1) ? 65536u : 1u);
-                                } else if ((long long)v < nbins) {
-                                    const long long k = (long long)chunk * E + e;
-                                    atomicAdd(&a.hist[k * nbins + v], 1ULL);
                                 } else {
-                                    n_over_cells++;
+                                    if ((u64)v > maxv) maxv = (u64)v;
+                                    if ((long long)v < nbins) {
+                                        const long long k = (long long)chunk * E + e;
+                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                    } else {
+                                        n_over_cells++;
+                                    }
                                 }
-                                acc[j][e] = __dadd_rn(acc[j][e], __dmul_rn((double)v, w));
+                                acc[j][e] = mean_add(acc[j][e], (double)v, w);
                             }
                         }
                     }
                 }
+            }
+        }
+    };
+
+    // Software pipeline, two register buffers: the loads of the next RB row groups are in flight
+    // while the current ones are processed (the compiler places counted s_waitcnt vmcnt).
+    {
+        long long g = wave;
+        if (g < ngroups) {
+            Buf bufA, bufB;
+            load_buf(bufA, g);
+            while (true) {
+                load_buf(bufB, g + S);
+                process_buf(bufA, g);
+                g += S;
+                if (g >= ngroups) break;
+                load_buf(bufA, g + S);
+                process_buf(bufB, g);
+                g += S;
+                if (g >= ngroups) break;
             }
         }
     }
@@ -330,16 +417,19 @@ struct ReduceArgs {
     u64* hist;
     long long nbins;
     u64* histV;
+    u64* status;
     long long K;
-    int C, B, BRW, TB, TBpad, CW, PW, E, multi;
+    int C, B, BRW, TB, TBpad, hoff, CW, PW, E, multi;
 };
 
 __global__ __launch_bounds__(256) void hist_reduce_kernel(ReduceArgs a) {
     __shared__ u64 shlo[4][64], shhi[4][64];
     const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;  // word index in the image
-    const long long used = a.TBpad + (long long)(a.B + 1) * a.BRW;
+    const long long used = a.hoff + (long long)(a.B + 1) * a.BRW;
+    const bool isV = idx < a.TB;
+    const bool isH = idx >= a.hoff + a.BRW && idx < used;  // skips the weight table and the sink row
     u64 lo = 0, hi = 0;
-    if (idx < used)
+    if (isV || isH)
         for (long long g = threadIdx.y; g < a.G; g += 4) {
             const u32 w = a.hist_part[g * a.part_words + idx];
             lo += w & 0xffffu;
@@ -348,26 +438,36 @@ __global__ __launch_bounds__(256) void hist_reduce_kernel(ReduceArgs a) {
     shlo[threadIdx.y][threadIdx.x] = lo;
     shhi[threadIdx.y][threadIdx.x] = hi;
     __syncthreads();
-    if (threadIdx.y != 0 || idx >= used) return;
+    if (threadIdx.y != 0) return;  // one full wave goes on
     lo = shlo[0][threadIdx.x] + shlo[1][threadIdx.x] + shlo[2][threadIdx.x] + shlo[3][threadIdx.x];
     hi = shhi[0][threadIdx.x] + shhi[1][threadIdx.x] + shhi[2][threadIdx.x] + shhi[3][threadIdx.x];
-    if (idx < a.TBpad) {  // row-total bins: plain 32-bit counters
+    u64 maxv = 0, maxt = 0;
+    if (isV) {  // row-total bins: plain 32-bit counters
         const u64 cnt = lo + (hi << 16);
-        if (cnt && idx < a.TB) a.histV[idx] += cnt;
-        return;
+        if (cnt) {
+            a.histV[idx] += cnt;
+            maxt = (u64)idx;
+        }
+    } else if (isH && (lo | hi)) {
+        const u32 h = (u32)(idx - a.hoff);
+        const u32 v = h / (u32)a.BRW;
+        const u32 wi = h - v * (u32)a.BRW;
+        const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
+        const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
+        const u32 chunk = a.multi ? cc : cc + 64u * j;
+        if (chunk < (u32)a.C) {
+            const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
+            if (lo) a.hist[k0 * a.nbins + v] += lo;
+            if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
+            maxv = v;
+        }
     }
-    if ((lo | hi) == 0) return;
-    const u32 h = (u32)(idx - a.TBpad);
-    const u32 v = h / (u32)a.BRW;
-    if (v == 0) return;  // sink row
-    const u32 wi = h - v * (u32)a.BRW;
-    const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
-    const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
-    const u32 chunk = a.multi ? cc : cc + 64u * j;
-    if (chunk >= (u32)a.C) return;
-    const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
-    if (lo) a.hist[k0 * a.nbins + v] += lo;
-    if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
+    maxv = dme_wave_max_u64(maxv);
+    maxt = dme_wave_max_u64(maxt);
+    if (threadIdx.x == 0) {
+        if (maxv) atomicMax(&a.status[4], maxv);
+        if (maxt) atomicMax(&a.status[5], maxt);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -430,7 +530,7 @@ constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workg
 constexpr int kMaxJ = 8;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, TBpad, block, lds_bytes, rows_per_wg;
+    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg;
     long long grid, part_words;
     bool multi;
 };
@@ -467,7 +567,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.block = (p.J * E > 16) ? 512 : 1024;
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
-    long long avail = kLdsBudgetBytes / 4 - TBpad - 4;
+    const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
+    const long long hoff = TBpad + 2 * WT;
+    long long avail = kLdsBudgetBytes / 4 - hoff - 4;
     long long B = avail / p.BRW - 1;
     if (B > nbins - 1) B = nbins - 1;
     if (B > 65535) B = 65535;
@@ -475,7 +577,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.B = (int)B;
     p.TB = (int)TB;
     p.TBpad = (int)TBpad;
-    p.part_words = (TBpad + (B + 1) * (long long)p.BRW + 3) & ~3LL;
+    p.WT = (int)WT;
+    p.hoff = (int)hoff;
+    p.part_words = (hoff + (B + 1) * (long long)p.BRW + 3) & ~3LL;
     long long lds = p.part_words * 4;
     const long long acc_bytes = (long long)p.block * E * 8;  // mean-accumulator exchange
     if (lds < acc_bytes) lds = acc_bytes;
@@ -533,6 +637,18 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     Plan p;
     int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, &p);
     if (rc) return rc;
+#ifdef DME_DEBUG_HOOKS
+    if (const char* e = getenv("DME_STATS_GRIDMUL")) {
+        long long m = atoi(e);
+        if (m > 0) {
+            long long grid = p.grid * m;
+            long long rpw = (N + grid - 1) / grid;
+            if (rpw < 64) rpw = 64;
+            p.grid = (N + rpw - 1) / rpw;
+            p.rows_per_wg = (int)rpw;
+        }
+    }
+#endif
     const long long init_bytes = (p.grid * K * 8 + 255) & ~255LL;
     const long long need = init_bytes + p.grid * p.part_words * 4;
     if (!workspace || workspace_bytes < need)
@@ -541,7 +657,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, 0};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     switch (p.E) {
@@ -556,9 +672,10 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     }
     if (rc) return rc;
     const int PW = p.E >= 2 ? p.E / 2 : 1;
-    ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, K,
-                  p.C, p.B, p.BRW, p.TB, p.TBpad, p.multi ? p.C : 64, PW, p.E, p.multi ? 1 : 0};
-    const long long used = p.TBpad + (long long)(p.B + 1) * p.BRW;
+    ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
+                  p.C, p.B, p.BRW, p.TB, p.TBpad, p.hoff, p.multi ? p.C : 64, PW, p.E,
+                  p.multi ? 1 : 0};
+    const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
     hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, 4), 0, s, ra);
     hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, 4), 0, s,
                        (const double*)workspace, p.grid, K, init_acc);
