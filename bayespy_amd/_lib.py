@@ -37,7 +37,7 @@ SIGNATURES = {
     "dme_predicted_step": (_int, [_f64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_predicted_step_alt": (_int, [_f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_solve": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _i64, _vp,
-                         _vp, _vp, _i64, _vp]),
+                         _vp, _vp, _vp, _i64, _vp]),
     "dme_synth_scratch_bytes": (_i64, [_i64]),
     "dme_synth_dirmult": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _u64, _i64, _vp, _i64, _vp]),
 }

@@ -109,7 +109,51 @@ struct BlockShared {
     DmeAcc acc[STEP_WAVES];
     double dbl[STEP_WAVES];
     int flag[STEP_WAVES];
+    // fused reduction (block_reduce_fused): up to 3 compensated sums, 4 plain sums, one flag
+    DmeAcc facc[3][STEP_WAVES];
+    double fdbl[4][STEP_WAVES];
+    int fflag[STEP_WAVES];
 };
+
+// One pass, two barriers: NA compensated sums, ND plain sums and an OR-flag reduced together, in a
+// fixed order (DPP inside a wave, then waves 0..15 in order).  Every thread gets the results.
+template <int NA, int ND>
+__device__ __forceinline__ void block_reduce_fused(DmeAcc (&a)[NA], double (&d)[ND], bool& flag,
+                                                   BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a[i] = dme_wave_sum_acc(a[i]);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = dme_wave_sum_f64(d[i]);
+    const int any = __any(flag);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) sh.facc[i][wave] = a[i];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) sh.fdbl[i][wave] = d[i];
+        sh.fflag[wave] = any;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        DmeAcc r = sh.facc[i][0];
+#pragma unroll
+        for (int w = 1; w < STEP_WAVES; ++w) r.add(sh.facc[i][w]);
+        a[i] = r;
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        double r = sh.fdbl[i][0];
+#pragma unroll
+        for (int w = 1; w < STEP_WAVES; ++w) r = __dadd_rn(r, sh.fdbl[i][w]);
+        d[i] = r;
+    }
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < STEP_WAVES; ++w) f |= sh.fflag[w];
+    flag = f != 0;
+    __syncthreads();
+}
 
 __device__ __forceinline__ DmeAcc block_sum_acc(DmeAcc v, BlockShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -247,9 +291,14 @@ struct Gathered {
     DmeAcc logsum;  // sum_k sum_n U log(.)     (block total)
     DmeAcc t0, t1;  // V sums
     double t2;
+    // by-products at the evaluated point, so that an accepted point needs no further reductions:
+    double gradSq;          // sum_k g_k^2                       (sqVectorSize, :104)
+    double numSum, denSum;  // sum g_k/d_k, sum 1/d_k            (getPredictedStep, :69-70)
+    bool zero_d;            // some d_k == 0 (ZeroDivisionError at :69)
 };
 
 // Per-column sums at the evaluated point -> g_out[k], d_out[k]; returns the block totals.
+// Two fused block reductions: the V sums first (the gradient needs them), then everything per k.
 __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambda, double* g_out,
                                 double* d_out, BlockShared& sh) {
     Gathered G;
@@ -257,21 +306,25 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambd
     // V = column K
     {
         const long long f = w.segfirst[K], l = w.segfirst[K + 1];
-        DmeAcc a0{0, 0}, a1{0, 0};
-        double a2 = 0.0;
+        DmeAcc a[2] = {{0, 0}, {0, 0}};
+        double d[1] = {0.0};
         for (long long s = f + tid; s < l; s += STEP_BLOCK) {
             const Partial p = w.part[s];
-            a0.add(DmeAcc{p.s0hi, p.s0lo});
-            a1.add(DmeAcc{p.s1hi, p.s1lo});
-            a2 = __dadd_rn(a2, p.s2);
+            a[0].add(DmeAcc{p.s0hi, p.s0lo});
+            a[1].add(DmeAcc{p.s1hi, p.s1lo});
+            d[0] = __dadd_rn(d[0], p.s2);
         }
-        G.t0 = block_sum_acc(a0, sh);
-        G.t1 = block_sum_acc(a1, sh);
-        G.t2 = block_sum(a2, sh);
+        bool none = false;
+        block_reduce_fused<2, 1>(a, d, none, sh);
+        G.t0 = a[0];
+        G.t1 = a[1];
+        G.t2 = d[0];
     }
     const double termToSubtract = G.t1.value();
     const double hs = __dmul_rn(lambda, A);  // hyperprior * sum(priorList)   DE/dme.py:46
-    DmeAcc ls{0, 0};
+    DmeAcc ls[1] = {{0, 0}};
+    double r[3] = {0.0, 0.0, 0.0};  // gradSq, numSum, denSum
+    bool zero = false;
     for (long long k = tid; k < K; k += STEP_BLOCK) {
         const long long f = w.segfirst[k], l = w.segfirst[k + 1];
         DmeAcc a0{0, 0}, a1{0, 0};
@@ -282,13 +335,26 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambd
             a1.add(DmeAcc{p.s1hi, p.s1lo});
             a2 = __dadd_rn(a2, p.s2);
         }
-        ls.add(a0);
+        ls[0].add(a0);
         double g = __dsub_rn(a1.value(), termToSubtract);  // :45
         g = __dadd_rn(g, hs);                              // :46
+        const double dk = -a2;                             // :60
         g_out[k] = g;
-        d_out[k] = -a2;                                    // :60
+        d_out[k] = dk;
+        r[0] = __dadd_rn(r[0], __dmul_rn(g, g));
+        if (dk == 0.0) {
+            zero = true;
+        } else {
+            r[1] = __dadd_rn(r[1], __ddiv_rn(g, dk));
+            r[2] = __dadd_rn(r[2], __ddiv_rn(1.0, dk));
+        }
     }
-    G.logsum = block_sum_acc(ls, sh);
+    block_reduce_fused<1, 3>(ls, r, zero, sh);
+    G.logsum = ls[0];
+    G.gradSq = r[0];
+    G.numSum = r[1];
+    G.denSum = r[2];
+    G.zero_d = zero;
     return G;
 }
 
@@ -360,18 +426,18 @@ __device__ bool logspace_trial(const double* alpha, const double* g, const doubl
 // sum(trial) and the positivity test of testTrialPriors (DE/dme.py:98-100)
 __device__ void finish_trial(Ctrl* ctrl, const double* trial, long long K, BlockShared& sh) {
     const int tid = threadIdx.x;
-    double a = 0.0;
+    DmeAcc none[1] = {{0, 0}};
+    double a[1] = {0.0};
     bool bad = false;
     for (long long k = tid; k < K; k += STEP_BLOCK) {
         const double t = trial[k];
-        a = __dadd_rn(a, t);
+        a[0] = __dadd_rn(a[0], t);
         if (t <= 0.0) bad = true;
     }
-    const double A = block_sum(a, sh);
-    const bool anybad = block_any(bad, sh);
+    block_reduce_fused<1, 1>(none, a, bad, sh);
     if (tid == 0) {
-        ctrl->A_trial = A;
-        ctrl->trial_valid = anybad ? 0 : 1;
+        ctrl->A_trial = a[0];
+        ctrl->trial_valid = bad ? 0 : 1;
     }
 }
 
@@ -410,8 +476,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
 
     double lossT = INFINITY;
     double hconstT = 0.0;
+    Gathered G{};
     if (valid) {
-        const Gathered G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
+        G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
         lossT = loss_from(G, A, lambda);
         hconstT = G.t2;
         n_evals += 1;
@@ -424,7 +491,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
             c->done = 1; c->exit_reason = reason; c->error = err; c->count = count;
             c->n_evals = n_evals; c->currentLoss = currentLoss;
             result[0] = reason; result[1] = count; result[2] = n_evals; result[3] = err;
+            result[6] = 1;  // done: what the host polls
             result[4] = c->launches + 1;
+            result[5] = __double_as_longlong(currentLoss);
             if (final_loss) final_loss[0] = currentLoss;
         }
     };
@@ -497,12 +566,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
         return;
     }
     count += 1;
-    double gs = 0.0;
-    for (long long k = tid; k < K; k += STEP_BLOCK) {
-        const double g = w.g_cur[k];
-        gs = __dadd_rn(gs, __dmul_rn(g, g));
-    }
-    const double gradSq = block_sum(gs, sh);  // :142
+    const double gradSq = G.gradSq;  // :142 — an accepted point is always an evaluated one
     if (count - 1 < trace_cap) {
         if (trace && tid == 0) {
             double* t = trace + (count - 1) * 4;
@@ -516,9 +580,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
         finish(1, 0);
         return;
     }
-    const bool ok = newton_trial(w.alpha_cur, w.g_cur, w.d_cur, hconst, K, w.alpha_trial, nullptr, sh);
-    if (!ok) { finish(0, DME_ERR_ZERO_DIVISION); return; }
-    __syncthreads();
+    // getPredictedStep (:67-72) from the sums gathered with the evaluation
+    if (G.zero_d || hconst == 0.0) { finish(0, DME_ERR_ZERO_DIVISION); return; }
+    const double dd = __dadd_rn(__ddiv_rn(1.0, hconst), G.denSum);
+    if (dd == 0.0) { finish(0, DME_ERR_ZERO_DIVISION); return; }
+    const double bb = __ddiv_rn(G.numSum, dd);
+    for (long long k = tid; k < K; k += STEP_BLOCK)
+        w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __ddiv_rn(__dsub_rn(bb, w.g_cur[k]), w.d_cur[k]));
     finish_trial(c, w.alpha_trial, K, sh);
     store_state(PH_NEWTON);
 }
@@ -542,14 +610,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long lon
     }
     const Gathered G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
     const double loss = loss_from(G, A, lambda);
-    double gs = 0.0;
     for (long long k = tid; k < K; k += STEP_BLOCK) {
-        const double g = w.g_trial[k];
-        gs = __dadd_rn(gs, __dmul_rn(g, g));
-        if (out_grad) out_grad[k] = g;
+        if (out_grad) out_grad[k] = w.g_trial[k];
         if (out_hdiag) out_hdiag[k] = w.d_trial[k];
     }
-    const double gradSq = block_sum(gs, sh);
+    const double gradSq = G.gradSq;
     if (tid == 0) {
         out_scalars[0] = -loss;
         out_scalars[1] = G.t2;
@@ -583,6 +648,17 @@ int check_common(const double* Uf, long long ldU, const long long* lenU, const d
         return dme_set_error(DME_ERR_WORKSPACE, "solver workspace: need %lld bytes, got %lld",
                              w->bytes, workspace_bytes);
     return DME_OK;
+}
+
+// 64 bytes of pinned host memory per host thread for the completion poll (never freed).
+long long* poll_buffer() {
+    static thread_local long long* buf = nullptr;
+    if (!buf) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+        buf = (long long*)p;
+    }
+    return buf;
 }
 
 unsigned eval_grid(long long nseg_max) {
@@ -651,8 +727,9 @@ extern "C" int dme_predicted_step_alt(double hconst, const double* hdiag, const 
 extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
                          int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
                          int64_t iterations, double hyperprior, double* trace, double* trace_alpha,
-                         int64_t trace_cap, int64_t* result, double* final_loss, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
+                         int64_t trace_cap, int64_t* result, int64_t* result_host,
+                         double* final_loss, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
     Ws w;
     int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
                           workspace, workspace_bytes, &w);
@@ -671,7 +748,12 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
     // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
     const long long max_pairs = (iterations + 2) * 450 + 16;
     long long pairs = 0;
-    int batch = 10;
+    // Typical solves take 5-15 evaluations.  The first batch is enqueued while earlier work on the
+    // stream (the statistics pass) still runs, so its launches cost the host nothing and a launch
+    // pair that finds the solve finished costs ~3 us of device time: make it cover most solves.
+    int batch = 16;
+    long long* pinned = poll_buffer();
+    if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
     long long done = 0;
     while (!done) {
         for (int i = 0; i < batch; ++i) {
@@ -685,15 +767,17 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
         }
         pairs += batch;
         DME_HIP_CHECK(hipGetLastError());
-        DME_HIP_CHECK(hipMemcpyAsync(&done, &w.ctrl->done, sizeof(long long), hipMemcpyDeviceToHost, s));
+        // one 64-byte copy brings the done flag (first word of Ctrl is not it: result[] is) ...
+        DME_HIP_CHECK(hipMemcpyAsync(pinned, result, 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
         DME_HIP_CHECK(hipStreamSynchronize(s));
+        done = pinned[6];
         if (!done && pairs > max_pairs)
             return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld evaluations", pairs);
-        if (batch < 64) batch *= 2;
+        batch = pairs < 64 ? 8 : 32;
     }
-    long long res[4] = {0, 0, 0, 0};
-    DME_HIP_CHECK(hipMemcpyAsync(res, result, sizeof(res), hipMemcpyDeviceToHost, s));
-    DME_HIP_CHECK(hipStreamSynchronize(s));
+    const long long* res = pinned;  // the last poll already brought the whole result block
+    if (result_host)
+        for (int i = 0; i < 8; ++i) result_host[i] = res[i];
     if (res[3] == DME_ERR_ZERO_DIVISION)
         return dme_set_error(DME_ERR_ZERO_DIVISION, "float division by zero (an all-zero column or empty V)");
     if (res[3] == DME_ERR_MATH_DOMAIN)

@@ -59,6 +59,11 @@ struct StatsArgs {
 #endif
 #define DBG(bit) ((DME_ABLATE) & (bit))
 
+// dwords of a vector load handled under one exec mask in the uint16 cell loop (1, 2 or 4)
+#ifndef DME_GROUP
+#define DME_GROUP 1
+#endif
+
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -277,20 +282,32 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                                 }
                             }
                     }
+                    // one exec-masked region per DME_GROUP dwords: a lane enters it when any of its
+                    // 2*DME_GROUP counts is non-zero; zero halves inside go to the sink row
+                    constexpr int QG = (ND % DME_GROUP == 0) ? DME_GROUP : 1;
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) {
-                        const u32 dw = b.d[rb][j][q];
-                        if (__builtin_expect(dw != 0, 1)) {  // some lane of the wave almost always is
-                            const u32 lo = dw & 0xffffu;
-                            const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
-                            if (!DBG(1)) atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb)), 1u);
-                            if (!DBG(2)) acc[j][2 * q] = mean_add(acc[j][2 * q], (double)lo, w);
-                            if constexpr (E >= 2) {
-                                const u32 hi = dw >> 16;
+                    for (int q0 = 0; q0 < ND; q0 += QG) {
+                        u32 any = b.d[rb][j][q0];
+#pragma unroll
+                        for (int t = 1; t < QG; ++t) any |= b.d[rb][j][q0 + t];
+                        if (__builtin_expect(any != 0, 1)) {  // some lane of the wave almost always is
+#pragma unroll
+                            for (int t = 0; t < QG; ++t) {
+                                const int q = q0 + t;
+                                const u32 dw = b.d[rb][j][q];
+                                const u32 lo = dw & 0xffffu;
+                                const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
                                 if (!DBG(1))
-                                    atomicAdd((u32*)(ldsHb + (__umul24(hi, binRowBytes) + wb)), 65536u);
-                                if (!DBG(2))
-                                    acc[j][2 * q + 1] = mean_add(acc[j][2 * q + 1], (double)hi, w);
+                                    atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb)), 1u);
+                                if (!DBG(2)) acc[j][2 * q] = mean_add(acc[j][2 * q], (double)lo, w);
+                                if constexpr (E >= 2) {
+                                    const u32 hi = dw >> 16;
+                                    if (!DBG(1))
+                                        atomicAdd((u32*)(ldsHb + (__umul24(hi, binRowBytes) + wb)),
+                                                  65536u);
+                                    if (!DBG(2))
+                                        acc[j][2 * q + 1] = mean_add(acc[j][2 * q + 1], (double)hi, w);
+                                }
                             }
                         }
                     }
@@ -390,26 +407,31 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     }
 }
 
-// init_acc[k] += sum over workgroups of part[g][k], in a fixed order: 4 interleaved slices of g
-// per column (threadIdx.y), combined 0+1+2+3 through LDS.
-__global__ __launch_bounds__(256) void init_reduce_kernel(const double* part, long long G,
-                                                          long long K, double* init_acc) {
-    __shared__ double sh[4][64];
+constexpr int RED_SLICES = 16;  // interleaved slices of workgroups per output (threadIdx.y)
+
+// init_acc[k] += sum over workgroups of part[g][k], in a fixed order: RED_SLICES interleaved slices
+// of g per column, combined in slice order through LDS.
+__global__ __launch_bounds__(64 * RED_SLICES) void init_reduce_kernel(const double* part,
+                                                                      long long G, long long K,
+                                                                      double* init_acc) {
+    __shared__ double sh[RED_SLICES][64];
     const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
     double s = 0.0;
     if (k < K)
-        for (long long g = threadIdx.y; g < G; g += 4) s = __dadd_rn(s, part[g * K + k]);
+        for (long long g = threadIdx.y; g < G; g += RED_SLICES) s = __dadd_rn(s, part[g * K + k]);
     sh[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && k < K) {
-        double t = __dadd_rn(__dadd_rn(sh[0][threadIdx.x], sh[1][threadIdx.x]),
-                             __dadd_rn(sh[2][threadIdx.x], sh[3][threadIdx.x]));
+        double t = sh[0][threadIdx.x];
+#pragma unroll
+        for (int y = 1; y < RED_SLICES; ++y) t = __dadd_rn(t, sh[y][threadIdx.x]);
         init_acc[k] = __dadd_rn(init_acc[k], t);
     }
 }
 
 // Sums the LDS histogram images of all workgroups and adds them into hist / histV.  One thread
-// column per image word (two packed 16-bit counters), 4 interleaved slices of workgroups per word.
+// column per image word (two packed 16-bit counters), RED_SLICES interleaved slices of workgroups
+// per word.
 // Every (k, v) bin belongs to exactly one word, so the final += needs no atomics.
 struct ReduceArgs {
     const u32* hist_part;
@@ -422,15 +444,15 @@ struct ReduceArgs {
     int C, B, BRW, TB, TBpad, hoff, CW, PW, E, multi;
 };
 
-__global__ __launch_bounds__(256) void hist_reduce_kernel(ReduceArgs a) {
-    __shared__ u64 shlo[4][64], shhi[4][64];
+__global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs a) {
+    __shared__ u64 shlo[RED_SLICES][64], shhi[RED_SLICES][64];
     const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;  // word index in the image
     const long long used = a.hoff + (long long)(a.B + 1) * a.BRW;
     const bool isV = idx < a.TB;
     const bool isH = idx >= a.hoff + a.BRW && idx < used;  // skips the weight table and the sink row
     u64 lo = 0, hi = 0;
     if (isV || isH)
-        for (long long g = threadIdx.y; g < a.G; g += 4) {
+        for (long long g = threadIdx.y; g < a.G; g += RED_SLICES) {
             const u32 w = a.hist_part[g * a.part_words + idx];
             lo += w & 0xffffu;
             hi += w >> 16;
@@ -439,8 +461,12 @@ __global__ __launch_bounds__(256) void hist_reduce_kernel(ReduceArgs a) {
     shhi[threadIdx.y][threadIdx.x] = hi;
     __syncthreads();
     if (threadIdx.y != 0) return;  // one full wave goes on
-    lo = shlo[0][threadIdx.x] + shlo[1][threadIdx.x] + shlo[2][threadIdx.x] + shlo[3][threadIdx.x];
-    hi = shhi[0][threadIdx.x] + shhi[1][threadIdx.x] + shhi[2][threadIdx.x] + shhi[3][threadIdx.x];
+    lo = hi = 0;
+#pragma unroll
+    for (int y = 0; y < RED_SLICES; ++y) {
+        lo += shlo[y][threadIdx.x];
+        hi += shhi[y][threadIdx.x];
+    }
     u64 maxv = 0, maxt = 0;
     if (isV) {  // row-total bins: plain 32-bit counters
         const u64 cnt = lo + (hi << 16);
@@ -676,8 +702,8 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
                   p.C, p.B, p.BRW, p.TB, p.TBpad, p.hoff, p.multi ? p.C : 64, PW, p.E,
                   p.multi ? 1 : 0};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
-    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, 4), 0, s, ra);
-    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, 4), 0, s,
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, RED_SLICES), 0, s, ra);
+    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, RED_SLICES), 0, s,
                        (const double*)workspace, p.grid, K, init_acc);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;

@@ -11,6 +11,7 @@ Reference mapping (DirichletEstimation/dirichletMultinomialEstimation.py = "DE/d
     DeviceUV.evaluate                 <- dirichLogProb / priorGradient / priorHessian* (:16-61)
     DeviceUV.solve                    <- findDirichletPriors (:126-190)
 """
+import ctypes
 import logging
 
 import numpy as np
@@ -137,30 +138,52 @@ class DeviceUV:
             if a.numel() != self.K:
                 raise ValueError(f"expected {self.K} alphas, got {a.numel()}")
             cap = max(iterations, 1)
-            trace = torch.zeros(cap * 4, dtype=torch.float64, device=self.device)
-            talpha = (torch.zeros(cap * self.K, dtype=torch.float64, device=self.device)
+            # one buffer: result[8] int64 | final loss | trace[cap][4]   (+ optional alphas trace)
+            buf = torch.empty(8 + 1 + cap * 4, dtype=torch.float64, device=self.device)
+            result = buf[:8].view(torch.int64)
+            floss = buf[8:9]
+            trace = buf[9:]
+            talpha = (torch.empty(cap * self.K, dtype=torch.float64, device=self.device)
                       if trace_alphas else None)
-            result = torch.zeros(8, dtype=torch.int64, device=self.device)
-            floss = torch.zeros(1, dtype=torch.float64, device=self.device)
+            host = (ctypes.c_int64 * 8)()
             ws, wsb = self.workspace()
             _lib.check(_lib.lib().dme_solve(
                 _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
                 _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(trace),
-                _ptr(talpha), cap, _ptr(result), _ptr(floss), ws, wsb, _stream()))
-            res = result.cpu().numpy()
-            n = int(res[1])
-            return {
-                "alpha": a.cpu().numpy(),
-                "alpha_device": a,
-                "exit": int(res[0]),
-                "n_iters": n,
-                "n_evals": int(res[2]),
-                "launches": int(res[4]),
-                "final_loss": float(floss.cpu()[0]),
-                "trace": trace.view(cap, 4)[:n].cpu().numpy(),
-                "trace_alpha": (talpha.view(cap, self.K)[:n].cpu().numpy()
-                                if talpha is not None else None),
-            }
+                _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
+                _stream()))
+            # dme_solve synchronised the stream and filled `host`: no further device round trip
+            return SolveResult(a, list(host), trace.view(cap, 4), talpha, cap, self.K)
+
+
+class SolveResult(dict):
+    """What findDirichletPriors returned, plus the trace.  Scalars are host values already;
+    arrays stay on the device until asked for (`alpha`, `trace`, `trace_alpha` copy on first use)."""
+
+    def __init__(self, alpha_dev, res, trace_dev, talpha_dev, cap, K):
+        import struct
+        super().__init__()
+        self._lazy = {
+            "alpha": lambda: alpha_dev.cpu().numpy(),
+            "trace": lambda: trace_dev[:res[1]].cpu().numpy(),
+            "trace_alpha": (lambda: talpha_dev.view(cap, K)[:res[1]].cpu().numpy())
+            if talpha_dev is not None else (lambda: None),
+        }
+        dict.update(self, {
+            "alpha_device": alpha_dev,
+            "exit": int(res[0]),
+            "n_iters": int(res[1]),
+            "n_evals": int(res[2]),
+            "launches": int(res[4]),
+            "final_loss": struct.unpack("d", struct.pack("q", res[5]))[0],
+        })
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            val = self._lazy[key]()
+            dict.__setitem__(self, key, val)
+            return val
+        raise KeyError(key)
 
 
 class DeviceStats:
@@ -176,10 +199,14 @@ class DeviceStats:
         self.nbins = max(int(max_count), 1) + 1
         self.tbins = max(int(max_total), 1) + 1
         with torch.cuda.device(self.device):
-            self.hist = torch.zeros(self.K * self.nbins, dtype=torch.int64, device=self.device)
-            self.histV = torch.zeros(self.tbins, dtype=torch.int64, device=self.device)
-            self.init_acc = torch.zeros(self.K, dtype=torch.float64, device=self.device)
-            self.status = torch.zeros(8, dtype=torch.int64, device=self.device)
+            # one zero-filled buffer (one memset): hist | histV | status | init_acc (fp64 zeros are
+            # all-zero bits)
+            nh, nv = self.K * self.nbins, self.tbins
+            buf = torch.zeros(nh + nv + 8 + self.K, dtype=torch.int64, device=self.device)
+            self.hist = buf[:nh]
+            self.histV = buf[nh:nh + nv]
+            self.status = buf[nh + nv:nh + nv + 8]
+            self.init_acc = buf[nh + nv + 8:].view(torch.float64)
         self._ws = None
 
     # -- capacity -------------------------------------------------------------------------------
@@ -340,12 +367,12 @@ class DeviceStats:
         ldU = max(self.nbins - 1, 1)
         capV = max(self.tbins - 1, 1)
         with torch.cuda.device(dev):
-            U = torch.zeros(K * ldU, dtype=torch.int64, device=dev)
-            Uf = torch.zeros(K * ldU, dtype=torch.float64, device=dev)
-            lenU = torch.zeros(K, dtype=torch.int64, device=dev)
-            V = torch.zeros(capV, dtype=torch.int64, device=dev)
-            Vf = torch.zeros(capV, dtype=torch.float64, device=dev)
-            lenV = torch.zeros(1, dtype=torch.int64, device=dev)
+            # the scan writes every entry (padding included): no zero fill needed
+            ibuf = torch.empty(K * ldU + capV + K + 1, dtype=torch.int64, device=dev)
+            U, V = ibuf[:K * ldU], ibuf[K * ldU:K * ldU + capV]
+            lenU, lenV = ibuf[K * ldU + capV:K * ldU + capV + K], ibuf[K * ldU + capV + K:]
+            fbuf = torch.empty(K * ldU + capV, dtype=torch.float64, device=dev)
+            Uf, Vf = fbuf[:K * ldU], fbuf[K * ldU:]
             _lib.check(_lib.lib().dme_suffix_scan(
                 _ptr(self.hist), K, self.nbins, _ptr(self.histV), self.tbins, _ptr(U), _ptr(Uf),
                 ldU, _ptr(lenU), _ptr(V), _ptr(Vf), _ptr(lenV), _stream()))

@@ -9,8 +9,9 @@
  *
  * Conventions
  *   - every pointer marked [dev] is a device pointer (hipMalloc / torch tensor data_ptr()),
- *     owned by the caller; the library allocates nothing and keeps no state between calls
- *     (dme_solve only: a few bytes of pinned host memory for its completion poll);
+ *     owned by the caller; the library allocates no device memory and keeps no state between
+ *     calls (dme_solve only: 64 bytes of pinned host memory per host thread for its completion
+ *     poll, allocated on first use);
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - return value: DME_OK or a DME_ERR_* code; the text is in dme_last_error() (thread-local);
  *   - all launches are asynchronous on `stream` unless the entry says it synchronises;
@@ -141,7 +142,10 @@ int dme_predicted_step_alt(double hconst, const double* hdiag, const double* gra
  *   trace_alpha [dev][trace_cap][K] or NULL: the priors logged at :143.
  *   result [dev][8] int64: [0] exit reason (1 = small gradient, 2 = small learn rate,
  *       3 = max iterations), [1] iterations, [2] loss evaluations, [3] error
- *       (0 / DME_ERR_ZERO_DIVISION / DME_ERR_MATH_DOMAIN), [4] kernel launches used.
+ *       (0 / DME_ERR_ZERO_DIVISION / DME_ERR_MATH_DOMAIN), [4] evaluation launches used,
+ *       [5] the bits of final_loss (double), [6] done flag.
+ *   result_host [host][8] or NULL: a copy of `result` in host memory, valid on return (saves the
+ *       caller a device-to-host copy).
  *   final_loss [dev][1] or NULL: getTotalLoss at the returned priors.
  * The host only re-enqueues batches of (evaluate, step) launches and polls a done flag once per
  * batch; every decision is taken on the device.  SYNCHRONISES `stream` before returning.
@@ -149,8 +153,8 @@ int dme_predicted_step_alt(double hconst, const double* hdiag, const double* gra
 int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
               const int64_t* lenV, int64_t K, double* alpha, int64_t iterations,
               double hyperprior, double* trace, double* trace_alpha, int64_t trace_cap,
-              int64_t* result, double* final_loss, void* workspace, int64_t workspace_bytes,
-              void* stream);
+              int64_t* result, int64_t* result_host, double* final_loss, void* workspace,
+              int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Synthetic count rows for benchmarks and tests (no reference counterpart: the reference's
