@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: two gloo ranks each hold the value histograms of their row shard (built by
+the oracle's closed form); allreduce_stats_tensors must give every rank the histograms of the whole
+matrix, integer-exact, whatever the per-rank extents."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hist_of(X, K):
+    """Value histograms + mean accumulator of a row block (numpy; what the stats kernel emits)."""
+    X = X.astype(np.int64)
+    nb = int(X.max()) + 1 if X.size else 1
+    tot = X.sum(axis=1)
+    tb = int(tot.max()) + 1 if X.size else 1
+    hist = np.zeros((K, nb), dtype=np.int64)
+    for k in range(K):
+        hist[k] = np.bincount(X[:, k], minlength=nb)
+    hist[:, 0] = 0
+    histV = np.bincount(tot, minlength=tb).astype(np.int64)
+    histV[0] = 0
+    acc = (X / (1.0 + tot)[:, None]).sum(axis=0)
+    status = np.zeros(8, dtype=np.int64)
+    status[0], status[4], status[5] = X.shape[0], X.max(initial=0), tot.max(initial=0)
+    return hist, histV, status, acc, nb, tb
+
+
+def _worker(rank, world, port, X, K, out):
+    sys.path.insert(0, ROOT)
+    from bayespy_amd.parallel import allreduce_stats_tensors, shard_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_rows(X.shape[0], rank, world)
+    hist, histV, status, acc, nb, tb = _hist_of(X[lo:hi], K)
+    res = allreduce_stats_tensors(torch.from_numpy(hist.reshape(-1)), torch.from_numpy(histV),
+                                  torch.from_numpy(status), torch.from_numpy(acc), K, nb, tb)
+    h, v, st, a, nb2, tb2 = res
+    out[rank] = (h.view(K, nb2).numpy().copy(), v.numpy().copy(), st.numpy().copy(),
+                 a.numpy().copy(), nb2, tb2)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_of_shard_histograms_is_exact(world):
+    rng = np.random.default_rng(11)
+    K, N = 6, 501
+    X = rng.integers(0, 9, size=(N, K)) * (rng.random((N, K)) < 0.5)
+    X[N - 1, 2] = 40  # only the last shard sees the largest count: extents differ between ranks
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), X, K, out), nprocs=world, join=True)
+    hist, histV, status, acc, nb, tb = _hist_of(X, K)
+    for r in range(world):
+        h, v, st, a, nb2, tb2 = out[r]
+        assert (nb2, tb2) == (nb, tb)
+        assert np.array_equal(h, hist) and np.array_equal(v, histV)
+        assert st[0] == N and st[4] == 40 and st[5] == status[5]
+        np.testing.assert_allclose(a, acc, rtol=1e-13)
+    # and the suffix scan of the reduced histograms is the reference's U/V
+    sys.path.insert(0, ROOT)
+    import oracle
+    ref = oracle.append_rows(X.astype(np.int32))
+    for k in range(K):
+        U_k = np.cumsum(hist[k][::-1])[::-1][1:]
+        assert U_k[:len(ref.U[k])].tolist() == ref.U[k].tolist() and not U_k[len(ref.U[k]):].any()
+    V = np.cumsum(histV[::-1])[::-1][1:]
+    assert V[:len(ref.V)].tolist() == ref.V.tolist()
