@@ -25,7 +25,10 @@
 namespace {
 
 constexpr int SEG = 256;         // terms per segment: 4 per lane
-constexpr int STEP_BLOCK = 1024;
+#ifndef DME_STEP_BLOCK
+#define DME_STEP_BLOCK 512  // 1024-thread single-workgroup kernels measured 2x slower per launch
+#endif
+constexpr int STEP_BLOCK = DME_STEP_BLOCK;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
 constexpr int EVAL_BLOCK = 256;
 
