@@ -83,6 +83,15 @@ __device__ __forceinline__ void load_chunk(const void* p, u32 (&d)[ND]) {
     }
 }
 
+// Returns x through an empty asm: address arithmetic of the rare global-atomic paths that depends
+// on it cannot be hoisted out of those paths into (spilled) loop-invariant registers.
+__device__ __forceinline__ int opaque(int x) {
+#ifndef DME_NO_OPAQUE
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 __device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
     u16x2 x = __builtin_bit_cast(u16x2, a), y = __builtin_bit_cast(u16x2, b);
     return __builtin_bit_cast(u32, __builtin_elementwise_min(x, y));
@@ -104,23 +113,26 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(x, y));
 }
 
-template <int J, int E>
+template <int J, int E, int ES>
 struct StatsCfg {
-    static constexpr int BLOCK = (J * E > 16) ? 512 : 1024;
-    static constexpr int RB = (J <= 2) ? 2 : 1;  // row groups per register buffer (two buffers)
+    // threads per workgroup (one workgroup per CU): 1024 leaves 128 VGPRs per lane, which the
+    // 16-column uint16 kernel fits; wider lanes (and int32's 16 columns) take 512 or 256.
+    static constexpr int BLOCK = (J * E >= 64) ? 256 : ((J * E > 16) ? 512 : 1024);
+    // row groups per register buffer (two buffers): enough 16-byte loads in flight per CU
+    static constexpr int RB = (J <= 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1);
 };
 
 // T: element type (unsigned short | int).  E: elements per vector load.  J: vectors per lane and
 // row.  MULTI: a wave carries R = 64/C rows at once (then J == 1).
 template <typename T, int E, int J, bool MULTI>
-__global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
+__global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     constexpr bool IS16 = sizeof(T) == 2;
     constexpr int BYTES = E * (int)sizeof(T);
     constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
     constexpr int PW = E >= 2 ? E / 2 : 1;          // LDS words per vector (2 columns per word)
-    constexpr int BLOCK = StatsCfg<J, E>::BLOCK;
+    constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T)>::BLOCK;
     constexpr int W = BLOCK / 64;
-    constexpr int RB = StatsCfg<J, E>::RB;
+    constexpr int RB = StatsCfg<J, E, (int)sizeof(T)>::RB;
     typedef typename std::conditional<IS16, u32, u64>::type SumT;
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -150,9 +162,11 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[j][e] = 0.0;
-    u32 n_over_cells = 0, n_over_rows = 0, n_neg = 0;
-    u64 maxv = 0, maxt = 0;  // only the rare global-atomic paths update these; the maxima of the
-                             // LDS-privatised bins are taken by hist_reduce_kernel
+    // Data-error counters and the maxima seen by the rare global-atomic paths live in LDS, not in
+    // registers (the maxima of the LDS-privatised bins are taken by hist_reduce_kernel):
+    // [1] cells >= nbins, [2] rows >= tbins, [3] negative cells, [4] max count, [5] max row total.
+    __shared__ u64 sh_stat[8];
+    if (tid < 8) sh_stat[tid] = 0;
     const u32 Bpk = (u32)a.B | ((u32)a.B << 16);
 
     const long long row0 = (long long)blockIdx.x * a.rows_per_wg;
@@ -196,30 +210,72 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
         SumT tot[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            SumT s = 0;
+            if constexpr (IS16) {
+                u32 s = 0;
 #pragma unroll
-            for (int j = 0; j < J; ++j)
+                for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int q = 0; q < ND; ++q) {
-                    if constexpr (IS16) {
-                        s = __builtin_amdgcn_sad_u16(b.d[rb][j][q], 0u, s);
+                    for (int q = 0; q < ND; ++q) s = __builtin_amdgcn_sad_u16(b.d[rb][j][q], 0u, s);
+                if constexpr (MULTI) {
+                    u32 incl = s;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        u32 up = __shfl_up(incl, dd);
+                        if (c >= dd) incl += up;
+                    }
+                    int last = r * C + C - 1;
+                    tot[rb] = __shfl(incl, last > 63 ? 63 : last);
+                } else {
+                    tot[rb] = dme_wave_sum_u32(s);
+                }
+            } else {
+                // Unsigned maximum of the lane's counts (a negative count reads as a huge value).
+                // While every count of the wave is below 2^20 the 32-bit sums cannot wrap
+                // (64 lanes x 64 counts x 2^20 = 2^32 is never reached with J*E <= 64 ... < 2^32)
+                // and the cheap reduction is exact; otherwise (rare) sum the positive parts in 64 bits.
+                u32 m = 0, s32 = 0;
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) {
+                        m = max(m, b.d[rb][j][q]);
+                        s32 += b.d[rb][j][q];
+                    }
+                if (__builtin_expect(!__any(m >= (1u << 20)), 1)) {
+                    if constexpr (MULTI) {
+                        u32 incl = s32;
+#pragma unroll
+                        for (int dd = 1; dd < 64; dd <<= 1) {
+                            u32 up = __shfl_up(incl, dd);
+                            if (c >= dd) incl += up;
+                        }
+                        int last = r * C + C - 1;
+                        tot[rb] = (SumT)__shfl(incl, last > 63 ? 63 : last);
                     } else {
-                        const int v = (int)b.d[rb][j][q];
-                        s += (SumT)(v > 0 ? v : 0);
+                        tot[rb] = (SumT)dme_wave_sum_u32(s32);
+                    }
+                } else {
+                    u64 s = 0;
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) {
+                            const int v = (int)b.d[rb][j][q];
+                            s += (u64)(v > 0 ? v : 0);
+                        }
+                    if constexpr (MULTI) {
+                        u64 incl = s;
+#pragma unroll
+                        for (int dd = 1; dd < 64; dd <<= 1) {
+                            u64 up = __shfl_up(incl, dd);
+                            if (c >= dd) incl += up;
+                        }
+                        int last = r * C + C - 1;
+                        tot[rb] = __shfl(incl, last > 63 ? 63 : last);
+                    } else {
+                        tot[rb] = dme_wave_sum_u64(s);
                     }
                 }
-            if constexpr (MULTI) {
-                SumT incl = s;
-#pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    SumT up = __shfl_up(incl, dd);
-                    if (c >= dd) incl += up;
-                }
-                int last = r * C + C - 1;
-                tot[rb] = __shfl(incl, last > 63 ? 63 : last);
-            } else {
-                if constexpr (IS16) tot[rb] = dme_wave_sum_u32(s);
-                else tot[rb] = dme_wave_sum_u64(s);
             }
         }
 #pragma unroll
@@ -235,9 +291,9 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                     if ((u64)total < (u64)TB) {
                         atomicAdd(&ldsV[(u32)total], 1u);
                     } else {
-                        if ((u64)total > maxt) maxt = total;
+                        atomicMax(&sh_stat[5], (u64)total);
                         if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
-                        else n_over_rows++;
+                        else atomicAdd(&sh_stat[2], 1ULL);
                     }
                 }
                 if ((u64)total < (u64)WT) w = ldsW[(u32)total];
@@ -247,10 +303,10 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                 if ((u64)total < (u64)TB) {
                     if (lane == 0 && total > 0 && !DBG(8)) atomicAdd(&ldsV[(u32)total], 1u);
                 } else if (!DBG(8)) {
-                    if ((u64)total > maxt) maxt = total;
+                    atomicMax(&sh_stat[5], (u64)total);
                     if (lane == 0) {
                         if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
-                        else n_over_rows++;
+                        else atomicAdd(&sh_stat[2], 1ULL);
                     }
                 }
                 if ((u64)total < (u64)WT) w = ldsW[(u32)total];
@@ -273,10 +329,10 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                             for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
                                 const u32 v = h ? (b.d[rb][j][q] >> 16) : (b.d[rb][j][q] & 0xffffu);
                                 if (v > (u32)B) {
-                                    const long long k = (long long)chunk * E + 2 * q + h;
-                                    if ((u64)v > maxv) maxv = v;
+                                    const long long k = (long long)opaque(chunk) * E + 2 * q + h;
+                                    atomicMax(&sh_stat[4], (u64)v);
                                     if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    else n_over_cells++;
+                                    else atomicAdd(&sh_stat[1], 1ULL);
                                     acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, w);
                                     b.d[rb][j][q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
                                 }
@@ -312,27 +368,47 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
                         }
                     }
                 } else {
+                    // int32: same structure as uint16.  Rare path first: a lane whose vector holds a
+                    // count > B (or a negative one, huge as unsigned) settles those cells here and
+                    // clears them, so the common code below sees counts in [0, B] only.
+                    u32 m = b.d[rb][j][0];
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const int v = (int)b.d[rb][j][e];
-                        if (v != 0) {
+                    for (int q = 1; q < ND; ++q) m = max(m, b.d[rb][j][q]);
+                    if (__builtin_expect(m > (u32)B, 0) && !DBG(4)) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const int v = (int)b.d[rb][j][e];
                             if (v < 0) {
-                                n_neg++;
-                            } else {
-                                if (v <= B) {
-                                    const u32 wb = laneWordByte + (u32)((j * PW + (e >> 1)) * CW) * 4u;
-                                    atomicAdd((u32*)(ldsHb + (__umul24((u32)v, binRowBytes) + wb)),
-                                              (e & 1) ? 65536u : 1u);
+                                atomicAdd(&sh_stat[3], 1ULL);
+                                b.d[rb][j][e] = 0;
+                            } else if (v > B) {
+                                atomicMax(&sh_stat[4], (u64)v);
+                                if ((long long)v < nbins) {
+                                    const long long k = (long long)opaque(chunk) * E + e;
+                                    atomicAdd(&a.hist[k * nbins + v], 1ULL);
                                 } else {
-                                    if ((u64)v > maxv) maxv = (u64)v;
-                                    if ((long long)v < nbins) {
-                                        const long long k = (long long)chunk * E + e;
-                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    } else {
-                                        n_over_cells++;
-                                    }
+                                    atomicAdd(&sh_stat[1], 1ULL);
                                 }
                                 acc[j][e] = mean_add(acc[j][e], (double)v, w);
+                                b.d[rb][j][e] = 0;
+                            }
+                        }
+                    }
+                    // two counts share an LDS word; a zero count goes to the sink row
+                    constexpr int EP = E >= 2 ? 2 : 1;
+#pragma unroll
+                    for (int e = 0; e < E; e += EP) {
+                        const u32 v0 = b.d[rb][j][e];
+                        const u32 v1 = EP == 2 ? b.d[rb][j][e + (EP - 1)] : 0u;
+                        if (__builtin_expect((v0 | v1) != 0, 1)) {
+                            const u32 wb = laneWordByte + (u32)((j * PW + (e >> 1)) * CW) * 4u;
+                            if (!DBG(1)) atomicAdd((u32*)(ldsHb + (__umul24(v0, binRowBytes) + wb)), 1u);
+                            if (!DBG(2)) acc[j][e] = mean_add(acc[j][e], (double)v0, w);
+                            if constexpr (EP == 2) {
+                                if (!DBG(1))
+                                    atomicAdd((u32*)(ldsHb + (__umul24(v1, binRowBytes) + wb)), 65536u);
+                                if (!DBG(2))
+                                    acc[j][e + (EP - 1)] = mean_add(acc[j][e + (EP - 1)], (double)v1, w);
                             }
                         }
                     }
@@ -394,17 +470,10 @@ __global__ __launch_bounds__((StatsCfg<J, E>::BLOCK)) void stats_dense_kernel(St
     }
 
     // ---- status ------------------------------------------------------------------------------
-    const u32 oc = dme_wave_sum_u32(n_over_cells), orow = dme_wave_sum_u32(n_over_rows);
-    const u32 ng = dme_wave_sum_u32(n_neg);
-    const u64 mv = dme_wave_max_u64(maxv), mt = dme_wave_max_u64(maxt);
-    if (lane == 0) {
-        if (oc) atomicAdd(&a.status[1], (u64)oc);
-        if (orow) atomicAdd(&a.status[2], (u64)orow);
-        if (ng) atomicAdd(&a.status[3], (u64)ng);
-        if (mv) atomicMax(&a.status[4], mv);
-        if (mt) atomicMax(&a.status[5], mt);
-        if (tid == 0) atomicAdd(&a.status[0], (u64)nrows);
-    }
+    // (the barriers of the accumulator exchange above order the LDS counters before these reads)
+    if (tid == 0) atomicAdd(&a.status[0], (u64)nrows);
+    if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
+    if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
 }
 
 constexpr int RED_SLICES = 16;  // interleaved slices of workgroups per output (threadIdx.y)
@@ -511,8 +580,10 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    u32 n_over_cells = 0, n_over_rows = 0, n_neg = 0;
-    u64 maxv = 0, maxt = 0, nrows = 0;
+    __shared__ u64 sh_stat[8];  // [1] cells >= nbins [2] rows >= tbins [3] bad entries [4],[5] maxima
+    if (threadIdx.x < 8) sh_stat[threadIdx.x] = 0;
+    __syncthreads();
+    u64 nrows = 0;
     for (long long i = wave0; i < N; i += nwaves) {
         const long long p0 = rowptr[i], p1 = rowptr[i + 1];
         u64 s = 0;
@@ -523,34 +594,29 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
         const u64 total = dme_wave_sum_u64(s);
         nrows++;
         if (lane == 0 && total > 0) {
-            if (total > maxt) maxt = total;
+            atomicMax(&sh_stat[5], total);
             if ((long long)total < tbins) atomicAdd(&histV[total], 1ULL);
-            else n_over_rows++;
+            else atomicAdd(&sh_stat[2], 1ULL);
         }
         const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
         for (long long p = p0 + lane; p < p1; p += 64) {
             const int v = vals[p];
             const long long k = colidx[p];
             if (v == 0) continue;
-            if (v < 0 || k < 0 || k >= K) { n_neg++; continue; }
-            if ((u64)v > maxv) maxv = (u64)v;
+            if (v < 0 || k < 0 || k >= K) { atomicAdd(&sh_stat[3], 1ULL); continue; }
+            atomicMax(&sh_stat[4], (u64)v);
             if ((long long)v < nbins) atomicAdd(&hist[k * nbins + v], 1ULL);
-            else n_over_cells++;
+            else atomicAdd(&sh_stat[1], 1ULL);
             atomicAdd(&init_acc[k], __dmul_rn((double)v, w));
         }
     }
-    const u32 oc = dme_wave_sum_u32(n_over_cells), orow = dme_wave_sum_u32(n_over_rows);
-    const u32 ng = dme_wave_sum_u32(n_neg);
-    const u64 mv = dme_wave_max_u64(maxv), mt = dme_wave_max_u64(maxt);
-    if (lane == 0) {
-        if (oc) atomicAdd(&status[1], (u64)oc);
-        if (orow) atomicAdd(&status[2], (u64)orow);
-        if (ng) atomicAdd(&status[3], (u64)ng);
-        if (mv) atomicMax(&status[4], mv);
-        if (mt) atomicMax(&status[5], mt);
-        if (nrows) atomicAdd(&status[0], nrows);
-    }
+    if (lane == 0 && nrows) atomicAdd(&status[0], nrows);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= 1 && t <= 3 && sh_stat[t]) atomicAdd(&status[t], sh_stat[t]);
+    if (t >= 4 && t <= 5 && sh_stat[t]) atomicMax(&status[t], sh_stat[t]);
 }
+
 
 constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
 constexpr int kMaxJ = 8;
@@ -590,7 +656,8 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const int PW = E >= 2 ? E / 2 : 1;
     const int CW = p.multi ? (int)C : 64;
     p.BRW = p.J * PW * CW;
-    p.block = (p.J * E > 16) ? 512 : 1024;
+    const int JE = p.J * E;
+    p.block = (JE >= 64) ? 256 : ((JE > 16) ? 512 : 1024);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
@@ -632,7 +699,7 @@ int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
     auto kern = stats_dense_kernel<T, E, J, MULTI>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB)
     DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kLdsBudgetBytes + 4096));
+                                      kLdsBudgetBytes + 1024));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(p.block), p.lds_bytes, s, a);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
