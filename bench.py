@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals "
+                         "with several ranks on one GPU)")
     ap.add_argument("--verify", action="store_true",
                     help="check size-independent properties of the statistics after the run")
     return ap.parse_args()
@@ -62,11 +65,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     K, N, M = args.k, args.rows, args.max_total
     tdtype = torch.uint16 if args.dtype == "u16" else torch.int32
@@ -135,7 +142,10 @@ def main():
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"stats_dense_{args.dtype}_bytes_per_launch")
+                tj = json.load(f)
+            # PMC traffic is per launch of the profiled shape only
+            if tj.get("N") == N and tj.get("K") == K:
+                traffic = tj.get(f"stats_dense_{args.dtype}_bytes_per_launch")
         except Exception:
             traffic = None
 
