@@ -319,9 +319,26 @@ class DeviceStats:
                 _stream()))
         return self
 
+    def check_async(self):
+        """Enqueues the copy of the status words to pinned host memory on the current stream and
+        returns at once; a later check() uses it if the stream has been synchronised in between
+        (dme_solve does), so the verdict costs no extra device round trip."""
+        if getattr(self, "_pinned", None) is None:
+            self._pinned = torch.empty(8, dtype=torch.int64, pin_memory=True)
+        self._pinned.copy_(self.status, non_blocking=True)
+        self._pending = torch.cuda.Event()
+        self._pending.record()
+
     def check(self):
-        """Synchronises and raises if the pass met data it could not count."""
-        st = self.status.cpu().numpy()
+        """Raises if the pass met data it could not count (bounds exceeded, negative cells);
+        returns rows processed and the maxima seen.  Synchronises unless check_async() ran."""
+        ev = getattr(self, "_pending", None)
+        if ev is not None:
+            ev.synchronize()  # already complete when the stream was synchronised after it
+            self._pending = None
+            st = self._pinned.numpy().copy()
+        else:
+            st = self.status.cpu().numpy()
         if st[3]:
             raise ValueError(f"{int(st[3])} negative counts (or column indices out of range)")
         if st[1] or st[2]:

@@ -103,7 +103,8 @@ def main():
         st.allreduce()
         uv = st.finalize()
         a0 = st.cli_init_alphas()
-        out = uv.solve(a0, args.iterations, 0.0, trace_alphas=False)
+        st.check_async()  # status words travel to pinned memory behind the scan
+        out = uv.solve(a0, args.iterations, 0.0, trace_alphas=False)  # synchronises the stream
         info = st.check()
         if timers is not None:
             timers.append((e0, e1))
