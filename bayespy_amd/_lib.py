@@ -14,6 +14,7 @@ ERR_WORKSPACE = 4
 ERR_ZERO_DIVISION = 5
 ERR_MATH_DOMAIN = 6
 ERR_INTERNAL = 7
+PARSE_FALLBACK = 100
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -38,6 +39,8 @@ SIGNATURES = {
     "dme_predicted_step_alt": (_int, [_f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_solve": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _i64, _vp,
                          _vp, _vp, _vp, _i64, _vp]),
+    "dme_parse_count_rows": (_i64, [ctypes.c_char_p, _i64]),
+    "dme_parse_counts": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _int]),
     "dme_synth_scratch_bytes": (_i64, [_i64]),
     "dme_synth_dirmult": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _u64, _i64, _vp, _i64, _vp]),
 }

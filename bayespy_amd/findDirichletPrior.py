@@ -29,6 +29,27 @@ from . import dirichletMultinomialEstimation as DME
 from . import samplingTools as Sample
 
 
+def _parse_fast(raw, delimiter, K):
+    """N x K int32 matrix from delimiter-separated text via dme_parse_counts, or None when the text
+    is outside the fast parser's grammar (the caller then runs the reference's row loop)."""
+    import ctypes
+
+    from . import _lib
+    if isinstance(raw, str):
+        raw = raw.encode()
+    if not raw or ord(delimiter) >= 128:
+        return None
+    L = _lib.lib()
+    n = L.dme_parse_count_rows(raw, len(raw))
+    out = np.empty((max(n, 1), K), dtype=np.int32)
+    got = ctypes.c_int64(0)
+    rc = L.dme_parse_counts(raw, len(raw), ord(delimiter), K, out.ctypes.data, n,
+                            ctypes.addressof(got), min(os.cpu_count() or 1, 16))
+    if rc != 0 or got.value != n or n == 0:
+        return None
+    return out[:n]
+
+
 def main(argv=None, stdin=None, stdout=None):
     stdin = sys.stdin if stdin is None else stdin
     stdout = sys.stdout if stdout is None else stdout
@@ -62,28 +83,46 @@ def main(argv=None, stdin=None, stdout=None):
     # Load Data
     #####
     csv.field_size_limit(1000000000)
-    reader = csv.reader(stdin, delimiter=options.delimiter)
     logging.debug("Loading data")
 
     dataObj = DME.CompressedRowData(K)
     sampleRate = float(options.sampleRate)
 
     idx = 0
-    for row in reader:
-        idx += 1
+    text = None
+    # Fast path (libdme_hip's multi-threaded parser): every row is kept (-s 1) and uncapped (no -M),
+    # so no per-row random draw decides anything.  Text outside its strict grammar falls back to
+    # the reference's own loop below, which keeps the reference's error behaviour.
+    if sampleRate >= 1.0 and options.M == sys.maxsize and len(options.delimiter) == 1:
+        raw = stdin.buffer.read() if hasattr(stdin, "buffer") else stdin.read()
+        X = _parse_fast(raw, options.delimiter, K)
+        if X is not None:
+            idx = X.shape[0]
+            for done in range(1000000, idx + 1, 1000000):
+                logging.debug("Loading Data: %s rows done" % done)
+            dataObj.appendMatrix(X)
+        else:
+            text = raw.decode() if isinstance(raw, bytes) else raw
 
-        if (random.random() < sampleRate):
-            data = list(map(int, row))
-            if (len(data) != K):
-                logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
-                logging.error("line %s: %s" % (idx, data))
+    if idx == 0:
+        import io
+        reader = csv.reader(io.StringIO(text) if text is not None else stdin,
+                            delimiter=options.delimiter)
+        for row in reader:
+            idx += 1
 
-            while sum(data) > options.M: data[Sample.drawCategory(data)] -= 1
+            if (random.random() < sampleRate):
+                data = list(map(int, row))
+                if (len(data) != K):
+                    logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
+                    logging.error("line %s: %s" % (idx, data))
 
-            # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
-            dataObj.appendRow(data, 1)
+                while sum(data) > options.M: data[Sample.drawCategory(data)] -= 1
 
-        if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
+                # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
+                dataObj.appendRow(data, 1)
+
+            if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
 
     dataLoadTime = time.time()
     logging.debug("loaded %s records into memory" % idx)

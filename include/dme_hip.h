@@ -36,6 +36,7 @@ extern "C" {
 #define DME_ERR_ZERO_DIVISION 5 /* the reference would raise ZeroDivisionError (DE/dme.py:69-71) */
 #define DME_ERR_MATH_DOMAIN 6   /* the reference would raise ValueError (math.log of x <= 0)     */
 #define DME_ERR_INTERNAL 7
+#define DME_PARSE_FALLBACK 100  /* dme_parse_counts: text outside the fast grammar, nothing parsed */
 
 int dme_abi_version(void);
 const char* dme_last_error(void);
@@ -155,6 +156,19 @@ int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
               double hyperprior, double* trace, double* trace_alpha, int64_t trace_cap,
               int64_t* result, int64_t* result_host, double* final_loss, void* workspace,
               int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Text ingestion for the CLI (host code, no GPU): replaces the csv.reader + int() row loop of
+ * DE/fdp.py:67-79 when every line holds exactly K integers ([ ]*[+-]?[0-9]+[ ]*) separated by one
+ * `delimiter` byte.  dme_parse_count_rows returns the number of lines (to size `out`);
+ * dme_parse_counts fills out[row*K + k] (host memory, int32) with `nthreads` threads.  Text the
+ * strict grammar does not cover returns DME_PARSE_FALLBACK: the caller then uses the reference's own
+ * loop, which keeps the reference's error behaviour (ValueError, ragged-row logging, ...).
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_parse_count_rows(const char* text /*[host]*/, int64_t nbytes);
+int dme_parse_counts(const char* text /*[host]*/, int64_t nbytes, int delimiter, int64_t K,
+                     int32_t* out /*[host]*/, int64_t out_rows, int64_t* n_rows /*[host]*/,
+                     int nthreads);
 
 /* ---------------------------------------------------------------------------------------------
  * Synthetic count rows for benchmarks and tests (no reference counterpart: the reference's

@@ -130,3 +130,52 @@ def test_draw_category_matches_reference_contract():
     for _ in range(3000):
         counts[drawCategory([1, 0, 3])] += 1
     assert counts[1] == 0 and 600 < counts[0] < 900
+
+
+def _parse(text, K, delim="\t", threads=4):
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    raw = text.encode()
+    n = L.dme_parse_count_rows(raw, len(raw))
+    out = np.full((max(n, 1), K), -7, dtype=np.int32)
+    got = ctypes.c_int64(0)
+    rc = L.dme_parse_counts(raw, len(raw), ord(delim), K, out.ctypes.data, n,
+                            ctypes.addressof(got), threads)
+    return rc, out[:got.value]
+
+
+def test_fast_parser_matches_the_reference_row_loop():
+    """dme_parse_counts vs csv.reader + int() (DE/fdp.py:67-79) on the reference's sample shapes."""
+    import csv
+    import io
+    from conftest import load_golden
+    fx = load_golden("test_csv")
+    for delim in ("\t", ","):
+        text = "".join(delim.join(str(v) for v in r) + "\n" for r in fx["rows"])
+        rc, X = _parse(text, 2, delim)
+        assert rc == 0
+        ref = [list(map(int, row)) for row in csv.reader(io.StringIO(text), delimiter=delim)]
+        assert X.tolist() == ref
+    # no trailing newline, CRLF, padding blanks, explicit signs
+    rc, X = _parse("1\t2\r\n +3 \t-4\n5\t6", 2)
+    assert rc == 0 and X.tolist() == [[1, 2], [3, -4], [5, 6]]
+    # a large text exercises the multi-threaded split (> 1 MiB)
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 100000, size=(60000, 7))
+    text = "\n".join("\t".join(map(str, r)) for r in big) + "\n"
+    assert len(text) > (1 << 20)
+    rc, X = _parse(text, 7, threads=8)
+    assert rc == 0 and np.array_equal(X, big)
+
+
+def test_fast_parser_gives_up_on_anything_else():
+    from bayespy_amd import _lib
+    for bad in ("1\t2\n\n3\t4\n",        # blank line
+                "1\t2\t3\n",             # too many fields
+                "1\n",                   # too few fields
+                "1\t2.0\n",              # not an integer
+                "1\t\"2\"\n",            # quoted field
+                "1\t1_0\n",              # python int() accepts this; the fast grammar does not
+                "1\t99999999999\n"):     # beyond int32
+        rc, X = _parse(bad, 2)
+        assert rc == _lib.PARSE_FALLBACK, bad

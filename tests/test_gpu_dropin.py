@@ -128,3 +128,42 @@ def test_cli_delimiter_and_hyperprior():
              stdin=io.StringIO(_rows_text(fx, ",")), stdout=out)
     got = [float(x) for x in out.getvalue().strip()[len("Final priors: ["):-1].split(",")]
     np.testing.assert_allclose(got, ref["final"], rtol=1e-9)
+
+
+def _run_cli(args, text):
+    from bayespy_amd import findDirichletPrior as cli
+    out = io.StringIO()
+    cli.main(args, stdin=io.StringIO(text), stdout=out)
+    line = out.getvalue().strip()
+    return [float(x) for x in line[len("Final priors: ["):-1].split(",")]
+
+
+def test_cli_fast_and_reference_row_loop_agree():
+    """Quoted fields are outside the fast parser's grammar: the same data then goes through the
+    reference's csv.reader loop and must give the same priors."""
+    fx = load_golden("test_csv")
+    plain = _rows_text(fx)
+    quoted = "".join('"%d"\t%d\n' % (r[0], r[1]) for r in fx["X"])
+    a = _run_cli(["-K", "2", "-L", "ERROR"], plain)
+    b = _run_cli(["-K", "2", "-L", "ERROR"], quoted)
+    assert a == b
+
+
+def test_cli_errors_are_the_references():
+    with pytest.raises(ValueError):          # int("x") at DE/fdp.py:79
+        _run_cli(["-K", "2", "-L", "ERROR"], "1\t2\n3\tx\n")
+    with pytest.raises(IndexError):          # a short row reaches row[k] in appendRow
+        _run_cli(["-K", "3", "-L", "CRITICAL"], "1\t2\t3\n4\t5\n")
+
+
+def test_cli_row_cap_and_sampling_paths():
+    import random
+    fx = load_golden("test_csv")
+    text = _rows_text(fx)
+    random.seed(1)
+    capped = _run_cli(["-K", "2", "-M", "10", "-L", "ERROR"], text)
+    assert len(capped) == 2 and all(a > 0 for a in capped)
+    random.seed(2)
+    sampled = _run_cli(["-K", "2", "-s", "0.5", "-L", "ERROR"], text)
+    full = _run_cli(["-K", "2", "-L", "ERROR"], text)
+    assert all(abs(s - f) / f < 0.5 for s, f in zip(sampled, full))
