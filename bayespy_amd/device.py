@@ -246,21 +246,27 @@ class DeviceStats:
             return self
         if X.stride(1) != 1:
             X = X.contiguous()
-        if X.dtype in (torch.uint16, torch.int16):
+        if X.dtype == torch.uint16:
             fn = _lib.lib().dme_stats_dense_u16
-            as_signed = X.view(torch.int16) if X.dtype == torch.uint16 else X
+            as_signed = X.view(torch.int16)
         elif X.dtype == torch.int32:
             fn = _lib.lib().dme_stats_dense_i32
             as_signed = X
         else:
             raise TypeError(f"unsupported dtype {X.dtype}: use uint16 or int32")
         if max_count is None or max_total is None:
-            # bounds are measured, not guessed (an extra read of X; avoid by passing them)
-            wide = as_signed.to(torch.int64)
-            if X.dtype in (torch.uint16, torch.int16):
-                wide = wide & 0xFFFF
-            max_count = int(wide.max()) if max_count is None else max_count
-            max_total = int(wide.sum(dim=1).max()) if max_total is None else max_total
+            # bounds are measured, not guessed (an extra read of X, in row blocks so that the
+            # widened copy stays small; avoid it by passing the bounds)
+            mc, mt = 0, 0
+            step = max(1, (64 << 20) // max(self.K, 1))
+            for lo in range(0, X.shape[0], step):
+                wide = as_signed[lo:lo + step].to(torch.int64)
+                if X.dtype == torch.uint16:
+                    wide = wide & 0xFFFF
+                mc = max(mc, int(wide.max()))
+                mt = max(mt, int(wide.sum(dim=1).max()))
+            max_count = mc if max_count is None else max_count
+            max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
         with torch.cuda.device(self.device):
             ws, wsb = self._workspace(X.shape[0])
@@ -402,6 +408,68 @@ class DeviceStats:
             _lib.check(_lib.lib().dme_cli_init_alphas(_ptr(self.init_acc), self.K, _ptr(a0),
                                                       _stream()))
         return a0
+
+
+class WeightedStats:
+    """fp64 value histograms of rows that carry a weight (appendRow(row, w), w != 1):
+    dme_stats_dense_weighted_i32 / dme_suffix_scan_weighted."""
+
+    def __init__(self, K, device=None):
+        self.device = require_gpu(device)
+        self.K = int(K)
+        self.nbins, self.tbins = 2, 2
+        self._alloc()
+
+    def _alloc(self):
+        d = self.device
+        self.histW = torch.zeros(self.K * self.nbins, dtype=torch.float64, device=d)
+        self.histVW = torch.zeros(self.tbins, dtype=torch.float64, device=d)
+        self.maxcol = torch.zeros(self.K, dtype=torch.int64, device=d)
+        self.maxtot = torch.zeros(1, dtype=torch.int64, device=d)
+        self.status = torch.zeros(8, dtype=torch.int64, device=d)
+
+    def reserve(self, max_count, max_total):
+        nb, tb = max(self.nbins, int(max_count) + 1), max(self.tbins, int(max_total) + 1)
+        if nb != self.nbins:
+            new = torch.zeros(self.K, nb, dtype=torch.float64, device=self.device)
+            new[:, :self.nbins] = self.histW.view(self.K, self.nbins)
+            self.histW, self.nbins = new.view(-1), nb
+        if tb != self.tbins:
+            new = torch.zeros(tb, dtype=torch.float64, device=self.device)
+            new[:self.tbins] = self.histVW
+            self.histVW, self.tbins = new, tb
+
+    def add_dense(self, X, weights, max_count, max_total):
+        """X: int32 device tensor N x K (contiguous rows); weights: float64 device tensor [N]."""
+        if X.dtype != torch.int32 or X.dim() != 2 or X.shape[1] != self.K or X.stride(1) != 1:
+            raise ValueError("weighted rows must be an int32 N x K device tensor")
+        if weights.dtype != torch.float64 or weights.numel() != X.shape[0]:
+            raise ValueError("weights must be float64, one per row")
+        self.reserve(max_count, max_total)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().dme_stats_dense_weighted_i32(
+                X.data_ptr(), _ptr(weights), X.shape[0], self.K, X.stride(0), _ptr(self.histW),
+                self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol), _ptr(self.maxtot),
+                _ptr(self.status), _stream()))
+
+    def check(self):
+        st = self.status.cpu().numpy()
+        if st[3]:
+            raise ValueError(f"{int(st[3])} negative counts")
+        if st[1] or st[2]:
+            raise ValueError("weighted statistics incomplete: bounds passed to add_dense too small")
+
+    def add_into(self, uv):
+        """Adds the weighted suffix sums into a DeviceUV (whose U/V stop being integers)."""
+        if uv.ldU < self.nbins - 1 or uv.capV < self.tbins - 1:
+            raise ValueError("DeviceUV too small for the weighted statistics")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().dme_suffix_scan_weighted(
+                _ptr(self.histW), self.K, self.nbins, _ptr(self.histVW), self.tbins,
+                _ptr(self.maxcol), _ptr(self.maxtot), _ptr(uv.Uf), uv.ldU, _ptr(uv.lenU),
+                _ptr(uv.Vf), uv.capV, _ptr(uv.lenV), _stream()))
+        uv.Ui = uv.Vi = None  # no longer exact integers
+        return uv
 
 
 def predicted_step(hconst, hdiag, grad, alphas=None, device=None):

@@ -33,6 +33,9 @@ class CompressedRowData:
         self.K = K
         self._pending = []       # host rows not yet on the device (lists of K ints)
         self._excess = []        # sum of the entries beyond column K of over-long rows
+        self._wpending = []      # rows appended with a weight != 1 ...
+        self._wweights = []      # ... and their weights
+        self._wstats = None      # WeightedStats
         self._stats = None       # DeviceStats
         self._uv = None          # DeviceUV cache
         self._lists = None       # (U, V) host cache
@@ -42,13 +45,18 @@ class CompressedRowData:
     def appendRow(self, row, weight):
         if (len(row) != self.K):
             logging.error("row must have K=" + str(self.K) + " counts")  # DE/dme.py:114
-        if weight != 1:
-            raise NotImplementedError(
-                "fractional / non-unit row weights are not supported yet (the reference's CLI "
-                "always passes weight 1, DE/fdp.py:90)")
         if len(row) < self.K:
             raise IndexError("list index out of range")  # row[k] at DE/dme.py:117
         r = [int(x) for x in row]
+        if weight != 1:
+            # U[k][j] += weight, V[j] += weight (DE/dme.py:119, :123): kept in fp64 histograms
+            if len(r) > self.K and sum(r[self.K:]) != 0:
+                raise NotImplementedError("over-long rows with a non-unit weight")
+            self._wpending.append(r[:self.K])
+            self._wweights.append(float(weight))
+            self._uv = None
+            self._lists = None
+            return
         # an over-long row still counts in full towards sum(row) (DE/dme.py:121)
         self._excess.append(sum(r[self.K:]))
         self._pending.append(r[:self.K])
@@ -97,7 +105,25 @@ class CompressedRowData:
             self._stats = _dev.DeviceStats(self.K, device=self._device)
         return self._stats
 
+    def _flush_weighted(self):
+        if not self._wpending:
+            return
+        import torch
+        X = np.asarray(self._wpending, dtype=np.int64).reshape(len(self._wpending), self.K)
+        w = np.asarray(self._wweights, dtype=np.float64)
+        self._wpending, self._wweights = [], []
+        if X.size and np.abs(X).max() >= 2**31:
+            raise OverflowError("counts do not fit int32")
+        st = self._ensure_stats()
+        if self._wstats is None:
+            self._wstats = _dev.WeightedStats(self.K, device=st.device)
+        self._wstats.add_dense(torch.from_numpy(X.astype(np.int32)).to(st.device),
+                               torch.from_numpy(w).to(st.device),
+                               max_count=int(X.max()) if X.size else 0,
+                               max_total=int(X.sum(axis=1).max()) if X.size else 0)
+
     def _flush(self):
+        self._flush_weighted()
         if not self._pending:
             return
         import torch
@@ -131,11 +157,16 @@ class CompressedRowData:
         if self._uv is None:
             st = self._ensure_stats()
             st.check()
+            if self._wstats is not None:
+                self._wstats.check()
+                st.reserve(self._wstats.nbins - 1, self._wstats.tbins - 1)
             self._uv = st.finalize()
+            if self._wstats is not None:
+                self._wstats.add_into(self._uv)
         return self._uv
 
     def _host_lists(self):
-        if self._lists is None or self._pending:
+        if self._lists is None or self._pending or self._wpending:
             self._lists = self._device_uv().to_lists()
         return self._lists
 

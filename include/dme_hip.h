@@ -101,6 +101,26 @@ int dme_suffix_scan(const uint64_t* hist /*[dev]*/, int64_t K, int64_t nbins,
                     int64_t* V /*[dev]*/, double* Vf /*[dev] or NULL*/,
                     int64_t* lenV /*[dev] [1]*/, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Weighted rows: appendRow(row, weight) with weight != 1 (DE/dme.py:119, :123 add `weight`; used
+ * with fractional weights by ConjugatePriorTools/dirichletMixtureEstimation.py:129-133).
+ *     histW[k*nbins + v] += weights[i] for x_ik == v;  histVW[t] += weights[i] for row total t
+ *     maxcol[k] = max(maxcol[k], x_ik), maxtot[0] likewise (len(U[k]) grows whatever the weight)
+ * dme_suffix_scan_weighted ADDS the reverse suffix sums into the fp64 U/V of dme_suffix_scan
+ * (Uf[k*ldU+n] += sum_{v>n} histW[k][v]) and raises lenU/lenV to maxcol/maxtot.  int32 rows only;
+ * status as for the dense entries ([0] rows, [1] cells >= nbins, [2] totals >= tbins, [3] negatives).
+ * ------------------------------------------------------------------------------------------- */
+int dme_stats_dense_weighted_i32(const int32_t* X /*[dev]*/, const double* weights /*[dev][N]*/,
+                                 int64_t N, int64_t K, int64_t ld, double* histW /*[dev]*/,
+                                 int64_t nbins, double* histVW /*[dev]*/, int64_t tbins,
+                                 int64_t* maxcol /*[dev][K]*/, int64_t* maxtot /*[dev][1]*/,
+                                 uint64_t* status /*[dev]*/, void* stream);
+int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t nbins, const double* histVW,
+                             int64_t tbins, const int64_t* maxcol, const int64_t* maxtot,
+                             double* Uf /*[dev]*/, int64_t ldU, int64_t* lenU /*[dev]*/,
+                             double* Vf /*[dev]*/, int64_t capV, int64_t* lenV /*[dev]*/,
+                             void* stream);
+
 /* DE/fdp.py:104-108: alpha0[k] = init_acc[k] / (sum(init_acc) + 0.01) + 0.01 */
 int dme_cli_init_alphas(const double* init_acc /*[dev]*/, int64_t K, double* alpha0 /*[dev]*/,
                         void* stream);

@@ -66,7 +66,8 @@ def _raise(rc):
 
 
 class Stats:
-    """Ragged U (list of int64 arrays), V (int64 array), init accumulator (float64[K])."""
+    """Ragged U (list of arrays), V (array) — int64 from appendRow with weight 1, float64 once
+    weighted rows were added — and the init accumulator (float64[K])."""
 
     def __init__(self, K, U, V, init_acc):
         self.K = K
@@ -77,9 +78,9 @@ class Stats:
     def flat(self):
         off = np.zeros(self.K + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(u) for u in self.U])
-        Uflat = (np.concatenate(self.U).astype(np.int64) if off[-1] > 0
-                 else np.zeros(1, dtype=np.int64))
-        return np.ascontiguousarray(Uflat), off, np.ascontiguousarray(self.V, dtype=np.int64)
+        Uflat = (np.concatenate(self.U).astype(np.float64) if off[-1] > 0
+                 else np.zeros(1, dtype=np.float64))
+        return np.ascontiguousarray(Uflat), off, np.ascontiguousarray(self.V, dtype=np.float64)
 
     def cli_init_alphas(self):
         a0 = np.zeros(self.K, dtype=np.float64)
@@ -89,9 +90,36 @@ class Stats:
 
 
 def stats_from_lists(U, V):
+    """U/V as the reference holds them (ints, or floats once weighted rows were appended)."""
     K = len(U)
-    return Stats(K, [np.asarray(u, dtype=np.int64) for u in U], np.asarray(V, dtype=np.int64),
-                 np.zeros(K))
+    return Stats(K, [np.asarray(u) for u in U], np.asarray(V), np.zeros(K))
+
+
+def append_rows_weighted(X, weights, stats=None):
+    """appendRow(row, w_i) for every row, literal loops in C; optionally on top of `stats`."""
+    X = np.ascontiguousarray(X, dtype=np.int32)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    N, K = X.shape
+    capU = max(int(X.max()) if X.size else 0, 1)
+    capV = max(int(X.sum(axis=1, dtype=np.int64).max()) if X.size else 0, 1)
+    if stats is not None:
+        capU = max(capU, max((len(u) for u in stats.U), default=0))
+        capV = max(capV, len(stats.V))
+    U = np.zeros((K, capU), dtype=np.float64)
+    lenU = np.zeros(K, dtype=np.int64)
+    V = np.zeros(capV, dtype=np.float64)
+    lenV = np.zeros(1, dtype=np.int64)
+    if stats is not None:
+        for k, u in enumerate(stats.U):
+            U[k, :len(u)] = u
+            lenU[k] = len(u)
+        V[:len(stats.V)] = stats.V
+        lenV[0] = len(stats.V)
+    rc = lib().oracle_append_rows_weighted_i32(
+        _p(X, ctypes.c_int32), _f64p(w), ctypes.c_int64(N), ctypes.c_int64(K), ctypes.c_int64(K),
+        _f64p(U), ctypes.c_int64(capU), _i64p(lenU), _f64p(V), ctypes.c_int64(capV), _i64p(lenV))
+    _raise(rc)
+    return Stats(K, [U[k, :lenU[k]].copy() for k in range(K)], V[:lenV[0]].copy(), np.zeros(K))
 
 
 def append_rows(X, capU=None, capV=None):
@@ -160,8 +188,8 @@ def _args(stats, alpha):
 def logprob(alpha, stats, hyperprior=0.0):
     Uflat, off, V, a = _args(stats, alpha)
     out = ctypes.c_double()
-    _raise(lib().oracle_logprob(_f64p(a), ctypes.c_int64(stats.K), _i64p(Uflat), _i64p(off),
-                                _i64p(V), ctypes.c_int64(len(V)), ctypes.c_double(hyperprior),
+    _raise(lib().oracle_logprob(_f64p(a), ctypes.c_int64(stats.K), _f64p(Uflat), _i64p(off),
+                                _f64p(V), ctypes.c_int64(len(V)), ctypes.c_double(hyperprior),
                                 ctypes.byref(out)))
     return out.value
 
@@ -169,8 +197,8 @@ def logprob(alpha, stats, hyperprior=0.0):
 def total_loss(alpha, stats, hyperprior=0.0):
     Uflat, off, V, a = _args(stats, alpha)
     out = ctypes.c_double()
-    _raise(lib().oracle_total_loss(_f64p(a), ctypes.c_int64(stats.K), _i64p(Uflat), _i64p(off),
-                                   _i64p(V), ctypes.c_int64(len(V)),
+    _raise(lib().oracle_total_loss(_f64p(a), ctypes.c_int64(stats.K), _f64p(Uflat), _i64p(off),
+                                   _f64p(V), ctypes.c_int64(len(V)),
                                    ctypes.c_double(hyperprior), ctypes.byref(out)))
     return out.value
 
@@ -178,8 +206,8 @@ def total_loss(alpha, stats, hyperprior=0.0):
 def gradient(alpha, stats, hyperprior=0.0):
     Uflat, off, V, a = _args(stats, alpha)
     g = np.zeros(stats.K)
-    _raise(lib().oracle_gradient(_f64p(a), ctypes.c_int64(stats.K), _i64p(Uflat), _i64p(off),
-                                 _i64p(V), ctypes.c_int64(len(V)), ctypes.c_double(hyperprior),
+    _raise(lib().oracle_gradient(_f64p(a), ctypes.c_int64(stats.K), _f64p(Uflat), _i64p(off),
+                                 _f64p(V), ctypes.c_int64(len(V)), ctypes.c_double(hyperprior),
                                  _f64p(g)))
     return g
 
@@ -187,7 +215,7 @@ def gradient(alpha, stats, hyperprior=0.0):
 def hconst(alpha, stats):
     Uflat, off, V, a = _args(stats, alpha)
     out = ctypes.c_double()
-    _raise(lib().oracle_hconst(_f64p(a), ctypes.c_int64(stats.K), _i64p(V),
+    _raise(lib().oracle_hconst(_f64p(a), ctypes.c_int64(stats.K), _f64p(V),
                                ctypes.c_int64(len(V)), ctypes.byref(out)))
     return out.value
 
@@ -195,7 +223,7 @@ def hconst(alpha, stats):
 def hdiag(alpha, stats):
     Uflat, off, V, a = _args(stats, alpha)
     h = np.zeros(stats.K)
-    _raise(lib().oracle_hdiag(_f64p(a), ctypes.c_int64(stats.K), _i64p(Uflat), _i64p(off),
+    _raise(lib().oracle_hdiag(_f64p(a), ctypes.c_int64(stats.K), _f64p(Uflat), _i64p(off),
                               _f64p(h)))
     return h
 
@@ -239,7 +267,7 @@ def find_priors(stats, init_alphas, iterations, hyperprior=0.0, eval_cap=4096):
     n_evals = ctypes.c_int64()
     reason = ctypes.c_int()
     rc = lib().oracle_find_priors(
-        _i64p(Uflat), _i64p(off), _i64p(V), ctypes.c_int64(K), ctypes.c_int64(len(V)), _f64p(a),
+        _f64p(Uflat), _i64p(off), _f64p(V), ctypes.c_int64(K), ctypes.c_int64(len(V)), _f64p(a),
         ctypes.c_int64(iterations), ctypes.c_double(hyperprior), _f64p(t_loss), _f64p(t_gsq),
         _f64p(t_alpha), ctypes.c_int64(cap), ctypes.byref(n_iters), ctypes.byref(n_evals),
         ctypes.byref(reason), _f64p(ev), ctypes.c_int64(eval_cap))

@@ -16,7 +16,9 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no fused multiply-add may be formed).
  *
  * Data layout: U is ragged, stored flat with offsets: U[k][n] = Uflat[off[k] + n],
- * len(U[k]) = off[k+1] - off[k].  Counts are int64 (Python ints in the reference).
+ * len(U[k]) = off[k+1] - off[k].  appendRow builds int64 counts (Python ints in the reference);
+ * the solver side takes U/V as doubles — exact for the integer case (the reference converts with
+ * float(...) or int*float, same value), and what weighted rows produce anyway.
  */
 #include <math.h>
 #include <stdint.h>
@@ -94,6 +96,30 @@ int oracle_append_rows_csr_i32(const int64_t* rowptr, const int32_t* colidx, con
     return ORACLE_OK;
 }
 
+/* appendRow(row, weight) with arbitrary weights (DE/dme.py:113-123 literally; U/V become floats as
+ * soon as a fractional weight is added).  U dense-padded doubles U[k*capU + j]. */
+int oracle_append_rows_weighted_i32(const int32_t* X, const double* weights, int64_t N, int64_t K,
+                                    int64_t ld, double* U, int64_t capU, int64_t* lenU, double* V,
+                                    int64_t capV, int64_t* lenV) {
+    for (int64_t i = 0; i < N; ++i) {
+        const int32_t* row = X + i * ld;
+        const double w = weights[i];
+        int64_t total = 0;
+        for (int64_t k = 0; k < K; ++k) {
+            int64_t x = row[k];
+            total += x;
+            if (x > capU) return ORACLE_CAPACITY;
+            double* Uk = U + k * capU;
+            for (int64_t j = 0; j < x; ++j) Uk[j] += w;
+            if (x > lenU[k]) lenU[k] = x;
+        }
+        if (total > capV) return ORACLE_CAPACITY;
+        for (int64_t j = 0; j < total; ++j) V[j] += w;
+        if (total > *lenV) *lenV = total;
+    }
+    return ORACLE_OK;
+}
+
 /* a3 (second half): DE/fdp.py:104-108.  priorSum = sum(priors) + 0.01; p/=priorSum; p+=0.01 */
 void oracle_cli_init_alphas(const double* init_acc, int64_t K, double* alpha0) {
     double s = 0.0;
@@ -112,23 +138,23 @@ static double py_sum(const double* a, int64_t K) { /* sum(list): sequential from
 }
 
 /* a4: dirichLogProb — DE/dme.py:16-29.  Returns ORACLE_MATH_DOMAIN where math.log would raise. */
-int oracle_logprob(const double* alpha, int64_t K, const int64_t* Uflat, const int64_t* off,
-                   const int64_t* V, int64_t lenV, double hyperprior, double* out) {
+int oracle_logprob(const double* alpha, int64_t K, const double* Uflat, const int64_t* off,
+                   const double* V, int64_t lenV, double hyperprior, double* out) {
     double total = 0.0;
     for (int64_t k = 0; k < K; ++k) {
-        const int64_t* Uk = Uflat + off[k];
+        const double* Uk = Uflat + off[k];
         int64_t n = off[k + 1] - off[k];
         for (int64_t i = 0; i < n; ++i) {
             double x = alpha[k] + (double)i;
             if (x <= 0.0) return ORACLE_MATH_DOMAIN;
-            total += (double)Uk[i] * log(x); /* :21 */
+            total += Uk[i] * log(x); /* :21 */
         }
     }
     double sumPrior = py_sum(alpha, K); /* :23 */
     for (int64_t i = 0; i < lenV; ++i) {
         double x = sumPrior + (double)i;
         if (x <= 0.0) return ORACLE_MATH_DOMAIN;
-        total -= (double)V[i] * log(x); /* :25 */
+        total -= V[i] * log(x); /* :25 */
     }
     total += py_sum(alpha, K) * hyperprior; /* :28 */
     *out = total;
@@ -136,8 +162,8 @@ int oracle_logprob(const double* alpha, int64_t K, const int64_t* Uflat, const i
 }
 
 /* getTotalLoss — DE/dme.py:83-84: -1 * dirichLogProb */
-int oracle_total_loss(const double* alpha, int64_t K, const int64_t* Uflat, const int64_t* off,
-                      const int64_t* V, int64_t lenV, double hyperprior, double* out) {
+int oracle_total_loss(const double* alpha, int64_t K, const double* Uflat, const int64_t* off,
+                      const double* V, int64_t lenV, double hyperprior, double* out) {
     double lp;
     int rc = oracle_logprob(alpha, K, Uflat, off, V, lenV, hyperprior, &lp);
     if (rc) return rc;
@@ -146,22 +172,22 @@ int oracle_total_loss(const double* alpha, int64_t K, const int64_t* Uflat, cons
 }
 
 /* a5: priorGradient — DE/dme.py:32-48 (note :46 adds hyperprior * sum(priorList)). */
-int oracle_gradient(const double* alpha, int64_t K, const int64_t* Uflat, const int64_t* off,
-                    const int64_t* V, int64_t lenV, double hyperprior, double* grad) {
+int oracle_gradient(const double* alpha, int64_t K, const double* Uflat, const int64_t* off,
+                    const double* V, int64_t lenV, double hyperprior, double* grad) {
     double termToSubtract = 0.0;
     for (int64_t i = 0; i < lenV; ++i) {
         double den = py_sum(alpha, K) + (double)i; /* :37 re-evaluates sum() every term */
         if (den == 0.0) return ORACLE_ZERO_DIVISION;
-        termToSubtract += (double)V[i] / den;
+        termToSubtract += V[i] / den;
     }
     for (int64_t j = 0; j < K; ++j) {
-        const int64_t* Uj = Uflat + off[j];
+        const double* Uj = Uflat + off[j];
         int64_t n = off[j + 1] - off[j];
         double r = 0.0;
         for (int64_t i = 0; i < n; ++i) {
             double den = alpha[j] + (double)i;
             if (den == 0.0) return ORACLE_ZERO_DIVISION;
-            r += (double)Uj[i] / den; /* :42 */
+            r += Uj[i] / den; /* :42 */
         }
         grad[j] = r;
     }
@@ -174,28 +200,28 @@ int oracle_gradient(const double* alpha, int64_t K, const int64_t* Uflat, const 
 }
 
 /* a6: priorHessianConst — DE/dme.py:52-53.  `x ** 2` on a Python float is libm pow(x, 2.0). */
-int oracle_hconst(const double* alpha, int64_t K, const int64_t* V, int64_t lenV, double* out) {
+int oracle_hconst(const double* alpha, int64_t K, const double* V, int64_t lenV, double* out) {
     double s = 0.0;
     for (int64_t i = 0; i < lenV; ++i) {
         double den = pow(py_sum(alpha, K) + (double)i, 2.0);
         if (den == 0.0) return ORACLE_ZERO_DIVISION;
-        s += (double)V[i] / den;
+        s += V[i] / den;
     }
     *out = s;
     return ORACLE_OK;
 }
 
 /* a7: priorHessianDiag — DE/dme.py:55-61 */
-int oracle_hdiag(const double* alpha, int64_t K, const int64_t* Uflat, const int64_t* off,
+int oracle_hdiag(const double* alpha, int64_t K, const double* Uflat, const int64_t* off,
                  double* hdiag) {
     for (int64_t k = 0; k < K; ++k) {
-        const int64_t* Uk = Uflat + off[k];
+        const double* Uk = Uflat + off[k];
         int64_t n = off[k + 1] - off[k];
         double r = 0.0;
         for (int64_t i = 0; i < n; ++i) {
             double den = pow(alpha[k] + (double)i, 2.0);
             if (den == 0.0) return ORACLE_ZERO_DIVISION;
-            r -= (double)Uk[i] / den; /* :60 */
+            r -= Uk[i] / den; /* :60 */
         }
         hdiag[k] = r;
     }
@@ -250,9 +276,9 @@ double oracle_sq_vector_size(const double* v, int64_t K) {
 }
 
 typedef struct {
-    const int64_t* Uflat;
+    const double* Uflat;
     const int64_t* off;
-    const int64_t* V;
+    const double* V;
     int64_t K, lenV;
     double hyperprior;
     int64_t n_evals;
@@ -277,7 +303,7 @@ static int test_trial(ctx_t* c, const double* trial, double* loss) {
  * (:145-147), 2 = "Converged with small learn rate" (:182-184), 3 = "Reached max iterations"
  * (:189-190).  trace_* (optional) record what the reference logs at :143 each iteration.
  * Returns ORACLE_OK or the code of the Python exception the reference would raise. */
-int oracle_find_priors(const int64_t* Uflat, const int64_t* off, const int64_t* V, int64_t K,
+int oracle_find_priors(const double* Uflat, const int64_t* off, const double* V, int64_t K,
                        int64_t lenV, double* alpha, int64_t iterations, double hyperprior,
                        double* trace_loss, double* trace_gradsq, double* trace_alpha,
                        int64_t trace_cap, int64_t* n_iters, int64_t* n_evals, int* exit_reason,

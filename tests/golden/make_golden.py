@@ -343,6 +343,29 @@ def main():
     np.savez_compressed(os.path.join(OUT, "dirmult_k50_X.npz"), X=X.astype(np.int32))
     dump(fx, "dirmult_k50.json")
 
+    # 10: weighted rows (appendRow(row, w), DE/dme.py:113-123 with fractional w, as the reference's
+    #     Dirichlet-mixture EM does, CPT/dirichletMixtureEstimation.py:129-133) ------------------
+    rows = read_rows(f"{REF}/ConjugatePriorTools/test.csv", "\t")[:300]
+    rw = np.random.default_rng(20260010)
+    weights = [float(w) for w in rw.random(len(rows))]
+    weights[5] = 0.0     # a zero-weight row still lengthens U / V
+    rows[5] = [70, 3]
+    wobj = DE.CompressedRowData(2)
+    for r, w in zip(rows[:100], weights[:100]):
+        wobj.appendRow(r, w)
+    for r in rows[100:200]:
+        wobj.appendRow(r, 1)          # mixed with unit-weight rows
+    for r, w in zip(rows[200:], weights[200:]):
+        wobj.appendRow(r, w)
+    init = [1.0, 1.0]
+    out, iters, ex, evals = traced_solve(DE, wobj, list(init), 50, 0)
+    dump({"name": "weighted_rows", "K": 2, "rows": rows, "weights": weights,
+          "unit_weight_span": [100, 200],
+          "U": [[float(x) for x in u] for u in wobj.U], "V": [float(x) for x in wobj.V],
+          "init": init, "final": out, "exit": ex, "n_iters": len(iters), "n_evals": len(evals),
+          "final_loss": float(DE.getTotalLoss(out, wobj, 0)),
+          "trace": iters}, "weighted_rows.json")
+
     # 9: CPT variant agrees with DE on test.csv with no hyperprior (third oracle) ---------
     rows = read_rows(f"{REF}/ConjugatePriorTools/test.csv", "\t")
     cobj = build_stats(CPT, rows, 2)

@@ -116,8 +116,8 @@ def test_row_buffering_semantics_on_host():
     obj = DME.CompressedRowData(3)
     with pytest.raises(IndexError):
         obj.appendRow([1, 2], 1)            # row[k] out of range, DE/dme.py:117
-    with pytest.raises(NotImplementedError):
-        obj.appendRow([1, 2, 3], 0.5)       # fractional weights: SURVEY 8(f) row 2
+    obj.appendRow([1, 2, 3], 0.5)           # fractional weights are kept apart (fp64 histograms)
+    assert obj._wpending == [[1, 2, 3]] and obj._wweights == [0.5]
     obj.appendRow([1, 0, 2, 4], 1)          # over-long row keeps its excess for the total
     assert obj._pending == [[1, 0, 2]] and obj._excess == [4]
 

@@ -167,3 +167,24 @@ def test_cli_row_cap_and_sampling_paths():
     sampled = _run_cli(["-K", "2", "-s", "0.5", "-L", "ERROR"], text)
     full = _run_cli(["-K", "2", "-L", "ERROR"], text)
     assert all(abs(s - f) / f < 0.5 for s, f in zip(sampled, full))
+
+
+def test_weighted_rows_match_reference():
+    """appendRow(row, w) with fractional / zero / unit weights mixed, as the reference's mixture EM
+    feeds it (CPT/dirichletMixtureEstimation.py:129-133): U/V within 1e-12 (fp64 sums in another
+    order), solve within 1e-9 of the reference-generated golden."""
+    import json, os
+    from conftest import GOLDEN
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    fx = json.load(open(os.path.join(GOLDEN, "weighted_rows.json")))
+    lo, hi = fx["unit_weight_span"]
+    obj = DME.CompressedRowData(2)
+    for i, (r, w) in enumerate(zip(fx["rows"], fx["weights"])):
+        obj.appendRow(r, 1 if lo <= i < hi else w)
+    assert [len(u) for u in obj.U] == [len(u) for u in fx["U"]]
+    for got, ref in zip(obj.U, fx["U"]):
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+    np.testing.assert_allclose(obj.V, fx["V"], rtol=1e-12)
+    out = DME.findDirichletPriors(obj, fx["init"], 50)
+    np.testing.assert_allclose(out, fx["final"], rtol=1e-9)
+    np.testing.assert_allclose(DME.getTotalLoss(out, obj), fx["final_loss"], rtol=1e-12)

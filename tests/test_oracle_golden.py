@@ -126,3 +126,21 @@ def test_csr_rows_match_dense(oracle):
     assert [list(map(int, u)) for u in st.U] == fx["U"]
     assert list(map(int, st.V)) == fx["V"]
     assert st.init_acc.tolist() == fx["init_acc"]
+
+
+def test_weighted_rows_bit_exact(oracle):
+    """appendRow(row, w) with fractional, zero and unit weights mixed (reference-generated golden)."""
+    import json, os
+    from conftest import GOLDEN
+    fx = json.load(open(os.path.join(GOLDEN, "weighted_rows.json")))
+    X = np.asarray(fx["rows"], dtype=np.int32)
+    w = np.asarray(fx["weights"], dtype=np.float64).copy()
+    lo, hi = fx["unit_weight_span"]
+    w[lo:hi] = 1.0
+    st = oracle.append_rows_weighted(X, w)
+    assert [u.tolist() for u in st.U] == fx["U"]
+    assert st.V.tolist() == fx["V"]
+    out = oracle.find_priors(st, fx["init"], 50, 0.0)
+    assert out["alpha"].tolist() == fx["final"]
+    assert out["n_iters"] == fx["n_iters"] and out["n_evals"] == fx["n_evals"]
+    assert oracle.total_loss(out["alpha"], st, 0.0) == fx["final_loss"]
