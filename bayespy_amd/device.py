@@ -284,6 +284,8 @@ class DeviceStats:
         Costs one extra pass; only awkward layouts come here."""
         per16 = 16 // X.element_size()
         Kp = -(-self.K // per16) * per16
+        if Kp // per16 > 64 * 8:
+            return self._add_dense_as_csr(X, max_count, max_total)
         Xp = torch.zeros((X.shape[0], Kp), dtype=X.dtype, device=self.device)
         Xp[:, :self.K] = X
         tmp = DeviceStats(Kp, max_count, max_total, device=self.device)
@@ -299,6 +301,23 @@ class DeviceStats:
         cut.histV, cut.status = tmp.histV, tmp.status
         cut.init_acc = tmp.init_acc[:self.K].contiguous()
         return self.merge_(cut)
+
+    def _add_dense_as_csr(self, X, max_count, max_total):
+        """Dense rows wider than the dense kernels take (K > 4096 uint16 / 2048 int32): compress to
+        CSR on the device (torch, row blocks) and use the CSR entry."""
+        step = max(1, (32 << 20) // max(self.K, 1))
+        for lo in range(0, X.shape[0], step):
+            blk = X[lo:lo + step]
+            if blk.dtype == torch.uint16:
+                blk = blk.view(torch.int16).to(torch.int32) & 0xFFFF
+            nz = torch.nonzero(blk)
+            counts = torch.bincount(nz[:, 0], minlength=blk.shape[0])
+            rowptr = torch.zeros(blk.shape[0] + 1, dtype=torch.int64, device=self.device)
+            rowptr[1:] = torch.cumsum(counts, 0)
+            self.add_csr(rowptr, nz[:, 1].to(torch.int32).contiguous(),
+                         blk[nz[:, 0], nz[:, 1]].to(torch.int32).contiguous(),
+                         max_count=max_count, max_total=max_total)
+        return self
 
     def add_csr(self, rowptr, colidx, vals, max_count=None, max_total=None):
         """Adds CSR rows (rowptr int64[N+1], colidx int32[nnz], vals int32[nnz], all on device)."""

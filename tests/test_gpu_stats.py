@@ -218,3 +218,20 @@ def test_large_synthetic_properties():
     half.check()
     assert torch.equal(half.hist, st.hist) and torch.equal(half.histV, st.histV)
     np.testing.assert_allclose(half.init_acc.cpu().numpy(), st.init_acc.cpu().numpy(), rtol=1e-12)
+
+
+def test_wide_dense_matrix_goes_through_csr(oracle):
+    """K beyond the dense kernels' range (8 vectors per lane) still works: the host layer
+    compresses the rows to CSR on the device."""
+    dev = _dev()
+    rng = np.random.default_rng(9)
+    N, K = 300, 6000
+    X = rng.integers(1, 30, size=(N, K)) * (rng.random((N, K)) < 0.01)
+    ref = oracle.append_rows(X.astype(np.int32))
+    for dtype in ("u16", "i32"):
+        st = dev.DeviceStats(K)
+        st.add_dense(_to_dev(X, dtype))
+        info = st.check()
+        assert info["rows"] == N
+        _assert_uv_equal(st.finalize(), ref)
+        np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
