@@ -43,6 +43,10 @@ SIGNATURES = {
                          _vp, _vp, _vp, _i64, _vp]),
     "dme_parse_count_rows": (_i64, [ctypes.c_char_p, _i64]),
     "dme_parse_counts": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _int]),
+    "dme_eval_cpt": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f64, _int, _vp, _vp, _vp,
+                            _vp, _i64, _vp]),
+    "dme_solve_cpt": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _f64, _int, _vp,
+                             _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dme_synth_scratch_bytes": (_i64, [_i64]),
     "dme_synth_dirmult": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _u64, _i64, _vp, _i64, _vp]),
 }

@@ -57,6 +57,49 @@ struct Partial {  // per segment
     double s0hi, s0lo, s1hi, s1lo, s2, pad;
 };
 
+// Prior terms on top of the Dirichlet-multinomial likelihood.
+//   lambda : the scalar hyperprior of DirichletEstimation (DE/dme.py:28 loss += lambda*A, :46
+//            gradient += lambda*A — the reference's own quirk, kept).
+//   beta,W : the (Beta, W) conjugate hyperprior of ConjugatePriorTools/dirichletMultinomialEstimation.py
+//            ("CPT/dme.py"): loss -= sum alpha_k Beta_k (:32-34), += W*(lgamma(A) - sum lgamma(alpha_k))
+//            (:36-38); gradient -= Beta_k (:58-60), += W*(psi(A) - psi(alpha_k)) (:62-64);
+//            hConst += W*psi'(A) (:74-75); hDiag -= W*psi'(alpha_k) (:84-86).
+//   loss_ignores_prior : CPT's getTotalLoss drops Beta and W (CPT/dme.py:109-110), so inside
+//            findDirichletPriors the loss has no prior term while gradient and Hessian do.
+struct Prior {
+    double lambda;
+    const double* beta;
+    double W;
+    int has_W;
+    int loss_ignores_prior;
+};
+
+// digamma / trigamma for x > 0: recurrence up to x >= 10, then the asymptotic series (next omitted
+// term < 1e-16).  The reference calls scipy.special.psi / polygamma(1, .) (CPT/dme.py:15-16).
+__device__ double dme_digamma(double x) {
+    double r = 0.0;
+    while (x < 10.0) {
+        r -= 1.0 / x;
+        x += 1.0;
+    }
+    const double f = 1.0 / (x * x);
+    const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 +
+                     f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+    return r + log(x) - 0.5 / x + t;
+}
+
+__device__ double dme_trigamma(double x) {
+    double r = 0.0;
+    while (x < 10.0) {
+        r += 1.0 / (x * x);
+        x += 1.0;
+    }
+    const double f = 1.0 / (x * x);
+    const double t = (1.0 / x) * f * (1.0 / 6.0 + f * (-1.0 / 30.0 + f * (1.0 / 42.0 + f * (-1.0 / 30.0 +
+                     f * (5.0 / 66.0 + f * (-691.0 / 2730.0 + f * (7.0 / 6.0)))))));
+    return r + 1.0 / x + 0.5 * f + t;
+}
+
 // workspace carve-up (all offsets 256-byte aligned)
 struct Ws {
     Ctrl* ctrl;
@@ -112,9 +155,9 @@ struct BlockShared {
     DmeAcc acc[STEP_WAVES];
     double dbl[STEP_WAVES];
     int flag[STEP_WAVES];
-    // fused reduction (block_reduce_fused): up to 3 compensated sums, 4 plain sums, one flag
+    // fused reduction (block_reduce_fused): up to 3 compensated sums, 6 plain sums, one flag
     DmeAcc facc[3][STEP_WAVES];
-    double fdbl[4][STEP_WAVES];
+    double fdbl[6][STEP_WAVES];
     int fflag[STEP_WAVES];
 };
 
@@ -298,12 +341,18 @@ struct Gathered {
     double gradSq;          // sum_k g_k^2                       (sqVectorSize, :104)
     double numSum, denSum;  // sum g_k/d_k, sum 1/d_k            (getPredictedStep, :69-70)
     bool zero_d;            // some d_k == 0 (ZeroDivisionError at :69)
+    double sumAlphaBeta;    // sum alpha_k Beta_k      (CPT/dme.py:32-34), 0 without Beta
+    double sumLgamma;       // sum lgamma(alpha_k)      (CPT/dme.py:38),    0 without W
 };
 
 // Per-column sums at the evaluated point -> g_out[k], d_out[k]; returns the block totals.
 // Two fused block reductions: the V sums first (the gradient needs them), then everything per k.
-__device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambda, double* g_out,
-                                double* d_out, BlockShared& sh) {
+// CPT = false compiles the (Beta, W) terms out, so the scalar-hyperprior kernels keep their
+// register budget (116 VGPRs against 256 + spills with digamma / trigamma / lgamma inlined).
+template <bool CPT>
+__device__ Gathered gather_eval(const Ws& w, long long K, double A, const Prior& pr,
+                                const double* alpha, double* g_out, double* d_out,
+                                BlockShared& sh) {
     Gathered G;
     const int tid = threadIdx.x;
     // V = column K
@@ -323,10 +372,16 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambd
         G.t1 = a[1];
         G.t2 = d[0];
     }
+    double psiA = 0.0;
+    if (CPT && pr.has_W) {
+        G.t2 = __dadd_rn(G.t2, __dmul_rn(pr.W, dme_trigamma(A)));  // CPT/dme.py:74-75
+        psiA = dme_digamma(A);
+    }
     const double termToSubtract = G.t1.value();
-    const double hs = __dmul_rn(lambda, A);  // hyperprior * sum(priorList)   DE/dme.py:46
+    const double hs = __dmul_rn(pr.lambda, A);  // hyperprior * sum(priorList)   DE/dme.py:46
     DmeAcc ls[1] = {{0, 0}};
-    double r[3] = {0.0, 0.0, 0.0};  // gradSq, numSum, denSum
+    constexpr int NR = CPT ? 5 : 3;
+    double r[NR] = {};  // gradSq, numSum, denSum, sum a*Beta, sum lgamma(a)
     bool zero = false;
     for (long long k = tid; k < K; k += STEP_BLOCK) {
         const long long f = w.segfirst[k], l = w.segfirst[k + 1];
@@ -341,7 +396,18 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambd
         ls[0].add(a0);
         double g = __dsub_rn(a1.value(), termToSubtract);  // :45
         g = __dadd_rn(g, hs);                              // :46
-        const double dk = -a2;                             // :60
+        double dk = -a2;                                   // :60
+        if (CPT && pr.beta) {
+            const double bk = pr.beta[k];
+            g = __dsub_rn(g, bk);                                          // CPT/dme.py:60
+            r[NR - 2] = __dadd_rn(r[NR - 2], __dmul_rn(alpha[k], bk));     // CPT/dme.py:34
+        }
+        if (CPT && pr.has_W) {
+            const double ak = alpha[k];
+            g = __dadd_rn(g, __dmul_rn(pr.W, __dsub_rn(psiA, dme_digamma(ak))));  // CPT/dme.py:64
+            dk = __dsub_rn(dk, __dmul_rn(pr.W, dme_trigamma(ak)));                // CPT/dme.py:86
+            r[NR - 1] = __dadd_rn(r[NR - 1], lgamma(ak));                         // CPT/dme.py:38
+        }
         g_out[k] = g;
         d_out[k] = dk;
         r[0] = __dadd_rn(r[0], __dmul_rn(g, g));
@@ -352,21 +418,28 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, double lambd
             r[2] = __dadd_rn(r[2], __ddiv_rn(1.0, dk));
         }
     }
-    block_reduce_fused<1, 3>(ls, r, zero, sh);
+    block_reduce_fused<1, NR>(ls, r, zero, sh);
     G.logsum = ls[0];
     G.gradSq = r[0];
     G.numSum = r[1];
     G.denSum = r[2];
     G.zero_d = zero;
+    G.sumAlphaBeta = CPT ? r[NR - 2] : 0.0;
+    G.sumLgamma = CPT ? r[NR - 1] : 0.0;
     return G;
 }
 
-__device__ __forceinline__ double loss_from(const Gathered& G, double A, double lambda) {
+template <bool CPT>
+__device__ __forceinline__ double loss_from(const Gathered& G, double A, const Prior& pr) {
     // total = sum U log - sum V log + sum(alpha)*lambda ; loss = -total     DE/dme.py:21-29, :84
     DmeAcc t = G.logsum;
     DmeAcc neg{-G.t0.hi, -G.t0.lo};
     t.add(neg);
-    t.add(__dmul_rn(A, lambda));
+    t.add(__dmul_rn(A, pr.lambda));
+    if (CPT && !pr.loss_ignores_prior) {
+        if (pr.beta) t.add(-G.sumAlphaBeta);                                         // CPT/dme.py:32-34
+        if (pr.has_W) t.add(__dmul_rn(pr.W, __dsub_rn(lgamma(A), G.sumLgamma)));   // CPT/dme.py:36-38
+    }
     return -t.value();
 }
 
@@ -459,8 +532,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
     finish_trial(w.ctrl, w.alpha_trial, K, sh);
 }
 
+template <bool CPT>
 __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, long long iterations,
-                                                          double lambda, double* trace,
+                                                          Prior pr, double* trace,
                                                           double* trace_alpha, long long trace_cap,
                                                           double* alpha_out, long long* result,
                                                           double* final_loss) {
@@ -481,8 +555,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
     double hconstT = 0.0;
     Gathered G{};
     if (valid) {
-        G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
-        lossT = loss_from(G, A, lambda);
+        G = gather_eval<CPT>(w, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh);
+        lossT = loss_from<CPT>(G, A, pr);
         hconstT = G.t2;
         n_evals += 1;
     }
@@ -595,7 +669,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
 }
 
 // dme_eval epilogue: publish the evaluated quantities
-__global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long long K, double lambda,
+template <bool CPT>
+__global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long long K, Prior pr,
                                                                   double* out_scalars,
                                                                   double* out_grad,
                                                                   double* out_hdiag) {
@@ -611,8 +686,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long lon
         if (tid == 0) { out_scalars[0] = NAN; out_scalars[1] = NAN; out_scalars[2] = A; out_scalars[3] = NAN; }
         return;
     }
-    const Gathered G = gather_eval(w, K, A, lambda, w.g_trial, w.d_trial, sh);
-    const double loss = loss_from(G, A, lambda);
+    const Gathered G = gather_eval<CPT>(w, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh);
+    const double loss = loss_from<CPT>(G, A, pr);
     for (long long k = tid; k < K; k += STEP_BLOCK) {
         if (out_grad) out_grad[k] = w.g_trial[k];
         if (out_hdiag) out_hdiag[k] = w.d_trial[k];
@@ -682,10 +757,12 @@ extern "C" int64_t dme_solver_workspace_bytes(int64_t K, int64_t ldU, int64_t ca
     return carve(nullptr, K, ldU, capV).bytes;
 }
 
-extern "C" int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
-                        int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
-                        double hyperprior, double* out_scalars, double* out_grad,
-                        double* out_hdiag, void* workspace, int64_t workspace_bytes, void* stream) {
+namespace {
+
+int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
+              const int64_t* lenV, int64_t K, const double* alpha, Prior pr, double* out_scalars,
+              double* out_grad, double* out_hdiag, void* workspace, int64_t workspace_bytes,
+              void* stream) {
     Ws w;
     int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
                           workspace, workspace_bytes, &w);
@@ -701,10 +778,36 @@ extern "C" int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, cons
     hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
                        w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
                        (long long)capV, (const long long*)lenV, (long long)K, w.alpha_trial, w.part);
-    hipLaunchKernelGGL(publish_eval_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (long long)K,
-                       hyperprior, out_scalars, out_grad, out_hdiag);
+    const bool cpt = pr.beta != nullptr || pr.has_W;
+    if (cpt)
+        hipLaunchKernelGGL(publish_eval_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+                           (long long)K, pr, out_scalars, out_grad, out_hdiag);
+    else
+        hipLaunchKernelGGL(publish_eval_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+                           (long long)K, pr, out_scalars, out_grad, out_hdiag);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
+}
+
+}  // namespace
+
+extern "C" int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                        int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                        double hyperprior, double* out_scalars, double* out_grad,
+                        double* out_hdiag, void* workspace, int64_t workspace_bytes, void* stream) {
+    const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
+    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
+                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                            int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                            const double* beta, double W, int has_W, double* out_scalars,
+                            double* out_grad, double* out_hdiag, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    const Prior pr{0.0, beta, W, has_W ? 1 : 0, 0};
+    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
+                     workspace, workspace_bytes, stream);
 }
 
 extern "C" int dme_predicted_step(double hconst, const double* hdiag, const double* grad, int64_t K,
@@ -727,12 +830,13 @@ extern "C" int dme_predicted_step_alt(double hconst, const double* hdiag, const 
     return DME_OK;
 }
 
-extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
-                         int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
-                         int64_t iterations, double hyperprior, double* trace, double* trace_alpha,
-                         int64_t trace_cap, int64_t* result, int64_t* result_host,
-                         double* final_loss, void* workspace, int64_t workspace_bytes,
-                         void* stream) {
+namespace {
+
+int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
+               const int64_t* lenV, int64_t K, double* alpha, int64_t iterations, Prior pr,
+               double* trace, double* trace_alpha, int64_t trace_cap, int64_t* result,
+               int64_t* result_host, double* final_loss, void* workspace, int64_t workspace_bytes,
+               void* stream) {
     Ws w;
     int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
                           workspace, workspace_bytes, &w);
@@ -758,15 +862,21 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
     long long* pinned = poll_buffer();
     if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
     long long done = 0;
+    const bool cpt = pr.beta != nullptr || pr.has_W;
     while (!done) {
         for (int i = 0; i < batch; ++i) {
             hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, w.ctrl, w.seg_k,
                                w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
                                (long long)capV, (const long long*)lenV, (long long)K,
                                w.alpha_trial, w.part);
-            hipLaunchKernelGGL(step_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (long long)K,
-                               (long long)iterations, hyperprior, trace, trace_alpha,
-                               (long long)trace_cap, alpha, (long long*)result, final_loss);
+            if (cpt)
+                hipLaunchKernelGGL(step_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+                                   (long long)K, (long long)iterations, pr, trace, trace_alpha,
+                                   (long long)trace_cap, alpha, (long long*)result, final_loss);
+            else
+                hipLaunchKernelGGL(step_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+                                   (long long)K, (long long)iterations, pr, trace, trace_alpha,
+                                   (long long)trace_cap, alpha, (long long*)result, final_loss);
         }
         pairs += batch;
         DME_HIP_CHECK(hipGetLastError());
@@ -787,4 +897,29 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
         return dme_set_error(DME_ERR_MATH_DOMAIN, "math domain error (non-positive initial alpha)");
     if (res[3] != 0) return dme_set_error(DME_ERR_INTERNAL, "solver error %lld", res[3]);
     return DME_OK;
+}
+
+}  // namespace
+
+extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                         int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                         int64_t iterations, double hyperprior, double* trace, double* trace_alpha,
+                         int64_t trace_cap, int64_t* result, int64_t* result_host,
+                         double* final_loss, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
+    return solve_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, iterations, pr, trace, trace_alpha,
+                      trace_cap, result, result_host, final_loss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dme_solve_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                             int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                             int64_t iterations, const double* beta, double W, int has_W,
+                             double* trace, double* trace_alpha, int64_t trace_cap, int64_t* result,
+                             int64_t* result_host, double* final_loss, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    // inside findDirichletPriors the loss carries no prior term (CPT/dme.py:109-110)
+    const Prior pr{0.0, beta, W, has_W ? 1 : 0, 1};
+    return solve_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, iterations, pr, trace, trace_alpha,
+                      trace_cap, result, result_host, final_loss, workspace, workspace_bytes, stream);
 }

@@ -107,8 +107,17 @@ class DeviceUV:
         return U, V
 
     # -- one evaluation: loss, gradient, Hessian parts (DE/dme.py:16-61) -------------------------
-    def evaluate(self, alpha, hyperprior=0.0):
-        """Returns (logprob, hconst, grad[K], hdiag[K], gradSq) as host values."""
+    def _beta(self, Beta):
+        if Beta is None:
+            return None
+        b = torch.as_tensor(np.asarray(Beta, dtype=np.float64)).to(self.device)
+        if b.numel() < self.K:
+            raise IndexError("list index out of range")  # Beta[i] at CPT/dme.py:34
+        return b[:self.K].contiguous()
+
+    def evaluate(self, alpha, hyperprior=0.0, Beta=None, W=None):
+        """Returns (logprob, hconst, grad[K], hdiag[K], gradSq) as host values.  With Beta / W the
+        (Beta, W) conjugate hyperprior of CPT/dme.py:20-87 replaces the scalar one."""
         with torch.cuda.device(self.device):
             a = torch.as_tensor(np.asarray(alpha, dtype=np.float64)).to(self.device)
             if a.numel() != self.K:
@@ -117,18 +126,27 @@ class DeviceUV:
             grad = torch.empty(self.K, dtype=torch.float64, device=self.device)
             hdiag = torch.empty(self.K, dtype=torch.float64, device=self.device)
             ws, wsb = self.workspace()
-            _lib.check(_lib.lib().dme_eval(
-                _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
-                _ptr(self.lenV), self.K, _ptr(a), float(hyperprior), _ptr(scal), _ptr(grad),
-                _ptr(hdiag), ws, wsb, _stream()))
+            if Beta is None and W is None:
+                _lib.check(_lib.lib().dme_eval(
+                    _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), float(hyperprior), _ptr(scal), _ptr(grad),
+                    _ptr(hdiag), ws, wsb, _stream()))
+            else:
+                if hyperprior:
+                    raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
+                b = self._beta(Beta)
+                _lib.check(_lib.lib().dme_eval_cpt(
+                    _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), _ptr(b), 0.0 if W is None else float(W),
+                    0 if W is None else 1, _ptr(scal), _ptr(grad), _ptr(hdiag), ws, wsb, _stream()))
             s = scal.cpu().numpy()
             return float(s[0]), float(s[1]), grad.cpu().numpy(), hdiag.cpu().numpy(), float(s[3])
 
     # -- the Newton loop (DE/dme.py:126-190) ----------------------------------------------------
-    def solve(self, init_alphas, iterations, hyperprior=0.0, trace_alphas=True):
+    def solve(self, init_alphas, iterations, hyperprior=0.0, trace_alphas=True, Beta=None, W=None):
         """Runs findDirichletPriors on the device.  Returns a dict: alpha (np.float64[K]),
         exit (1/2/3), n_iters, n_evals, final_loss, trace (n_iters x 4: loss, gradSq, branch,
-        learnRate), trace_alpha (n_iters x K or None)."""
+        learnRate), trace_alpha (n_iters x K or None).  With Beta / W: CPT/dme.py:156-219."""
         iterations = int(iterations)
         with torch.cuda.device(self.device):
             if isinstance(init_alphas, torch.Tensor):
@@ -147,11 +165,22 @@ class DeviceUV:
                       if trace_alphas else None)
             host = (ctypes.c_int64 * 8)()
             ws, wsb = self.workspace()
-            _lib.check(_lib.lib().dme_solve(
-                _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
-                _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(trace),
-                _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
-                _stream()))
+            if Beta is None and W is None:
+                _lib.check(_lib.lib().dme_solve(
+                    _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(trace),
+                    _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
+                    _stream()))
+            else:
+                if hyperprior:
+                    raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
+                b = self._beta(Beta)
+                _lib.check(_lib.lib().dme_solve_cpt(
+                    _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), iterations, _ptr(b),
+                    0.0 if W is None else float(W), 0 if W is None else 1, _ptr(trace),
+                    _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
+                    _stream()))
             # dme_solve synchronised the stream and filled `host`: no further device round trip
             return SolveResult(a, list(host), trace.view(cap, 4), talpha, cap, self.K)
 

@@ -50,6 +50,54 @@ def _parse_fast(raw, delimiter, K):
     return out[:n]
 
 
+def load_data(stdin, K, sampleRate, M, delimiter):
+    """The load loop of DE/fdp.py:66-93 -> (CompressedRowData, rows read)."""
+    #####
+    # Load Data
+    #####
+    csv.field_size_limit(1000000000)
+    logging.debug("Loading data")
+
+    dataObj = DME.CompressedRowData(K)
+
+    idx = 0
+    text = None
+    # Fast path (libdme_hip's multi-threaded parser): every row is kept (-s 1) and uncapped (no -M),
+    # so no per-row random draw decides anything.  Text outside its strict grammar falls back to
+    # the reference's own loop below, which keeps the reference's error behaviour.
+    if sampleRate >= 1.0 and M == sys.maxsize and len(delimiter) == 1:
+        raw = stdin.buffer.read() if hasattr(stdin, "buffer") else stdin.read()
+        X = _parse_fast(raw, delimiter, K)
+        if X is not None:
+            idx = X.shape[0]
+            for done in range(1000000, idx + 1, 1000000):
+                logging.debug("Loading Data: %s rows done" % done)
+            dataObj.appendMatrix(X)
+        else:
+            text = raw.decode() if isinstance(raw, bytes) else raw
+
+    if idx == 0:
+        import io
+        reader = csv.reader(io.StringIO(text) if text is not None else stdin,
+                            delimiter=delimiter)
+        for row in reader:
+            idx += 1
+
+            if (random.random() < sampleRate):
+                data = list(map(int, row))
+                if (len(data) != K):
+                    logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
+                    logging.error("line %s: %s" % (idx, data))
+
+                while sum(data) > M: data[Sample.drawCategory(data)] -= 1
+
+                # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
+                dataObj.appendRow(data, 1)
+
+            if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
+    return dataObj, idx
+
+
 def main(argv=None, stdin=None, stdout=None):
     stdin = sys.stdin if stdin is None else stdin
     stdout = sys.stdout if stdout is None else stdout
@@ -79,50 +127,7 @@ def main(argv=None, stdin=None, stdout=None):
     hyperprior = float(options.H)
     logging.debug("Hyperprior (lambda) = " + str(hyperprior))
 
-    #####
-    # Load Data
-    #####
-    csv.field_size_limit(1000000000)
-    logging.debug("Loading data")
-
-    dataObj = DME.CompressedRowData(K)
-    sampleRate = float(options.sampleRate)
-
-    idx = 0
-    text = None
-    # Fast path (libdme_hip's multi-threaded parser): every row is kept (-s 1) and uncapped (no -M),
-    # so no per-row random draw decides anything.  Text outside its strict grammar falls back to
-    # the reference's own loop below, which keeps the reference's error behaviour.
-    if sampleRate >= 1.0 and options.M == sys.maxsize and len(options.delimiter) == 1:
-        raw = stdin.buffer.read() if hasattr(stdin, "buffer") else stdin.read()
-        X = _parse_fast(raw, options.delimiter, K)
-        if X is not None:
-            idx = X.shape[0]
-            for done in range(1000000, idx + 1, 1000000):
-                logging.debug("Loading Data: %s rows done" % done)
-            dataObj.appendMatrix(X)
-        else:
-            text = raw.decode() if isinstance(raw, bytes) else raw
-
-    if idx == 0:
-        import io
-        reader = csv.reader(io.StringIO(text) if text is not None else stdin,
-                            delimiter=options.delimiter)
-        for row in reader:
-            idx += 1
-
-            if (random.random() < sampleRate):
-                data = list(map(int, row))
-                if (len(data) != K):
-                    logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
-                    logging.error("line %s: %s" % (idx, data))
-
-                while sum(data) > options.M: data[Sample.drawCategory(data)] -= 1
-
-                # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
-                dataObj.appendRow(data, 1)
-
-            if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
+    dataObj, idx = load_data(stdin, K, float(options.sampleRate), options.M, options.delimiter)
 
     dataLoadTime = time.time()
     logging.debug("loaded %s records into memory" % idx)

@@ -177,6 +177,25 @@ int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
               int64_t* result, int64_t* result_host, double* final_loss, void* workspace,
               int64_t workspace_bytes, void* stream);
 
+/* The same two entries with the (Beta, W) conjugate hyperprior of
+ * ConjugatePriorTools/dirichletMultinomialEstimation.py ("CPT/dme.py") instead of the scalar one:
+ *   beta [dev][K] or NULL, W used when has_W != 0.
+ * dme_eval_cpt backs CPT's dirichLogProb (:20-39, prior terms included), priorGradient (:42-66),
+ * priorHessianConst (:70-76), priorHessianDiag (:78-87).  dme_solve_cpt is CPT's
+ * findDirichletPriors (:156-219); as there, the loss it compares drops Beta and W
+ * (getTotalLoss, :109-110) while gradient and Hessian carry them.  digamma / trigamma are
+ * evaluated on the device (recurrence + asymptotic series, ~1e-16). */
+int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                 int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                 const double* beta /*[dev][K] or NULL*/, double W, int has_W,
+                 double* out_scalars /*[dev][4]*/, double* out_grad, double* out_hdiag,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+int dme_solve_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                  int64_t capV, const int64_t* lenV, int64_t K, double* alpha, int64_t iterations,
+                  const double* beta /*[dev][K] or NULL*/, double W, int has_W, double* trace,
+                  double* trace_alpha, int64_t trace_cap, int64_t* result, int64_t* result_host,
+                  double* final_loss, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Text ingestion for the CLI (host code, no GPU): replaces the csv.reader + int() row loop of
  * DE/fdp.py:67-79 when every line holds exactly K integers ([ ]*[+-]?[0-9]+[ ]*) separated by one

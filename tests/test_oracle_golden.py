@@ -144,3 +144,31 @@ def test_weighted_rows_bit_exact(oracle):
     assert out["alpha"].tolist() == fx["final"]
     assert out["n_iters"] == fx["n_iters"] and out["n_evals"] == fx["n_evals"]
     assert oracle.total_loss(out["alpha"], st, 0.0) == fx["final_loss"]
+
+
+# ---- (Beta, W) conjugate hyperprior: oracle/cpt.py against the reference's CPT module ------------
+def _cpt_cases():
+    fx = load_golden("cpt_hyperprior")
+    return fx, list(range(len(fx["cases"])))
+
+
+@pytest.mark.parametrize("idx", _cpt_cases()[1])
+def test_cpt_oracle_matches_reference(idx):
+    from oracle import cpt
+    fx = load_golden("cpt_hyperprior")
+    c = fx["cases"][idx]
+    ds = fx["datasets"][c["data"]]
+    d = cpt.UV(ds["U"], ds["V"])
+    for f in c["funcs"]:
+        np.testing.assert_allclose(cpt.log_prob(f["alpha"], d, c["Beta"], c["W"]), f["logprob"], rtol=1e-13)
+        np.testing.assert_allclose(cpt.total_loss(f["alpha"], d, c["Beta"], c["W"]), f["loss"], rtol=1e-13)
+        np.testing.assert_allclose(cpt.gradient(f["alpha"], d, c["Beta"], c["W"]), f["grad"],
+                                   rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(cpt.hconst(f["alpha"], d, c["W"]), f["hconst"], rtol=1e-13)
+        np.testing.assert_allclose(cpt.hdiag(f["alpha"], d, c["W"]), f["hdiag"], rtol=1e-13)
+    s = c["solve"]
+    out = cpt.find_priors(d, c["init"], 50, c["Beta"], c["W"])
+    assert out["exit"] == s["exit"] and out["n_iters"] == len(s["trace"])
+    np.testing.assert_allclose(out["alpha"], s["final"], rtol=1e-9)
+    np.testing.assert_allclose([t["loss"] for t in out["trace"]], [t["loss"] for t in s["trace"]],
+                               rtol=1e-12)
