@@ -565,59 +565,6 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// CSR rows.  One wave per row: lanes stride over the row's stored entries, the row total is a wave
-// reduction, every entry then adds 1 to hist[col][val] (64-bit global atomic; bag-of-words data
-// has K far beyond what LDS can privatise) and val*w to the per-workgroup... — the mean accumulator
-// is a global fp64 atomic here (K is too large for registers), so unlike the dense kernels its
-// last bits depend on arrival order.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr, const int* colidx,
-                                                        const int* vals, long long N, long long K,
-                                                        u64* hist, long long nbins, u64* histV,
-                                                        long long tbins, double* init_acc,
-                                                        u64* status) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    __shared__ u64 sh_stat[8];  // [1] cells >= nbins [2] rows >= tbins [3] bad entries [4],[5] maxima
-    if (threadIdx.x < 8) sh_stat[threadIdx.x] = 0;
-    __syncthreads();
-    u64 nrows = 0;
-    for (long long i = wave0; i < N; i += nwaves) {
-        const long long p0 = rowptr[i], p1 = rowptr[i + 1];
-        u64 s = 0;
-        for (long long p = p0 + lane; p < p1; p += 64) {
-            const int v = vals[p];
-            s += (u64)(v > 0 ? v : 0);
-        }
-        const u64 total = dme_wave_sum_u64(s);
-        nrows++;
-        if (lane == 0 && total > 0) {
-            atomicMax(&sh_stat[5], total);
-            if ((long long)total < tbins) atomicAdd(&histV[total], 1ULL);
-            else atomicAdd(&sh_stat[2], 1ULL);
-        }
-        const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
-        for (long long p = p0 + lane; p < p1; p += 64) {
-            const int v = vals[p];
-            const long long k = colidx[p];
-            if (v == 0) continue;
-            if (v < 0 || k < 0 || k >= K) { atomicAdd(&sh_stat[3], 1ULL); continue; }
-            atomicMax(&sh_stat[4], (u64)v);
-            if ((long long)v < nbins) atomicAdd(&hist[k * nbins + v], 1ULL);
-            else atomicAdd(&sh_stat[1], 1ULL);
-            atomicAdd(&init_acc[k], __dmul_rn((double)v, w));
-        }
-    }
-    if (lane == 0 && nrows) atomicAdd(&status[0], nrows);
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= 1 && t <= 3 && sh_stat[t]) atomicAdd(&status[t], sh_stat[t]);
-    if (t >= 4 && t <= 5 && sh_stat[t]) atomicMax(&status[t], sh_stat[t]);
-}
-
-
 constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
 constexpr int kMaxJ = 8;
 
@@ -801,27 +748,4 @@ extern "C" int dme_stats_dense_i32(const int32_t* X, int64_t N, int64_t K, int64
                                    int64_t workspace_bytes, void* stream) {
     return stats_dense<int>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
                             (u64*)status, workspace, workspace_bytes, stream);
-}
-
-extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, const int32_t* vals,
-                                 int64_t N, int64_t K, uint64_t* hist, int64_t nbins,
-                                 uint64_t* histV, int64_t tbins, double* init_acc, uint64_t* status,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
-    (void)workspace;
-    (void)workspace_bytes;
-    DME_REQUIRE(N >= 0 && K >= 1, "bad shape N=%lld K=%lld", (long long)N, (long long)K);
-    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
-    DME_REQUIRE(hist && histV && init_acc && status, "null output pointer");
-    if (N == 0) return DME_OK;
-    DME_REQUIRE(rowptr && colidx && vals, "null CSR pointer");
-    int cus = dme_device_cus();
-    if (cus <= 0) cus = 256;
-    long long waves = N < (long long)cus * 32 ? N : (long long)cus * 32;
-    long long grid = (waves + 3) / 4;
-    hipLaunchKernelGGL(stats_csr_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)rowptr, colidx, vals, (long long)N, (long long)K,
-                       (u64*)hist, (long long)nbins, (u64*)histV, (long long)tbins, init_acc,
-                       (u64*)status);
-    DME_HIP_CHECK(hipGetLastError());
-    return DME_OK;
 }

@@ -237,6 +237,7 @@ class DeviceStats:
             self.status = buf[nh + nv:nh + nv + 8]
             self.init_acc = buf[nh + nv + 8:].view(torch.float64)
         self._ws = None
+        self._csr_ws = None
 
     # -- capacity -------------------------------------------------------------------------------
     def reserve(self, max_count, max_total):
@@ -366,11 +367,20 @@ class DeviceStats:
             cs[1:] = torch.cumsum(vals.to(torch.int64), 0)
             max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
         self.reserve(max_count, max_total)
+        nnz = colidx.numel()
         with torch.cuda.device(self.device):
+            need = _lib.lib().dme_stats_csr_workspace_bytes(N, nnz, self.K)
+            ws, wsb = 0, 0
+            if need > 0:
+                if self._csr_ws is None or self._csr_ws.numel() < need + 256:
+                    self._csr_ws = None
+                    self._csr_ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+                off = (-self._csr_ws.data_ptr()) % 256
+                ws, wsb = self._csr_ws.data_ptr() + off, self._csr_ws.numel() - off
             _lib.check(_lib.lib().dme_stats_csr_i32(
-                _ptr(rowptr), _ptr(colidx), _ptr(vals), N, self.K, _ptr(self.hist), self.nbins,
-                _ptr(self.histV), self.tbins, _ptr(self.init_acc), _ptr(self.status), 0, 0,
-                _stream()))
+                _ptr(rowptr), _ptr(colidx), _ptr(vals), N, nnz, self.K, _ptr(self.hist),
+                self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc), _ptr(self.status),
+                ws, wsb, _stream()))
         return self
 
     def check_async(self):

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""BASELINE configs[3]: K = 50 000 bag-of-words rows in CSR, one GPU's shard.
+
+Input generator (torch, on the device; benchmark input, not the product path) + a timing loop
+around the CSR statistics entry (dme_stats_csr_i32) and the rest of the pipeline.
+
+  doc length n_i ~ clip(LogNormal(ln 120, 0.6), 1, 2000)
+  words      ~ Dirichlet-multinomial(n_i, alpha),  alpha_k = 50 * Zipf(1.07) weights (sum 50)
+               drawn as a Polya urn: token t is a fresh draw from alpha/50 with probability
+               50/(50+t), else a copy of a uniformly chosen earlier token of the same row
+  every column non-empty: one extra single-word row per missing word
+  seed 20260004 (+ rank);  colidx int32, vals int32, rowptr int64
+
+  python benchmarks/bow_csr.py [--rows 1000000] [--k 50000] [--steps 5] [--solve]
+Prints one JSON line: nnz, algorithmic bytes (nnz*8 + (N+1)*8), ms and GB/s of the statistics pass.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def zipf_alpha(K, s=1.07, total=50.0):
+    import numpy as np
+    w = np.arange(1, K + 1, dtype=np.float64) ** (-s)
+    return total * w / w.sum()
+
+
+def generate(N, K, seed=20260004, device="cuda", chunk=500_000, s=1.07, total=50.0,
+             shuffle_columns=True):
+    """Returns (rowptr int64[N'+1], colidx int32[nnz], vals int32[nnz]) on the device, N' >= N
+    (rows appended for words nobody drew).  shuffle_columns: word frequency rank is not the
+    column index (as in a real vocabulary)."""
+    import numpy as np
+    import torch
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    alpha = zipf_alpha(K, s, total)
+    cdf = torch.from_numpy(np.cumsum(alpha) / alpha.sum()).to(dev)
+    perm = None
+    if shuffle_columns:
+        perm = torch.from_numpy(np.random.default_rng(seed).permutation(K)).to(dev)
+    cols, vals, lens = [], [], []
+    for lo in range(0, N, chunk):
+        n_rows = min(chunk, N - lo)
+        ln = torch.empty(n_rows, dtype=torch.float64, device=dev).normal_(math.log(120.0), 0.6, generator=g)
+        n = ln.exp().floor().clamp_(1, 2000).to(torch.int64)
+        start = torch.cumsum(n, 0) - n
+        T = int(n.sum())
+        row = torch.repeat_interleave(torch.arange(n_rows, device=dev), n, output_size=T)
+        t = torch.arange(T, device=dev) - start[row]
+        u = torch.rand(T, dtype=torch.float64, device=dev, generator=g)
+        fresh = u * (total + t.to(torch.float64)) < total
+        u2 = torch.rand(T, dtype=torch.float64, device=dev, generator=g)
+        parent = start[row] + (u2 * t.to(torch.float64)).floor().to(torch.int64)
+        ptr = torch.where(fresh, torch.arange(T, device=dev), parent)
+        del parent, u2
+        for _ in range(12):  # pointer jumping: chains are at most 2000 long
+            ptr = ptr[ptr]
+        u3 = torch.rand(T, dtype=torch.float64, device=dev, generator=g)
+        word = torch.searchsorted(cdf, u3).clamp_(max=K - 1)
+        word = word[ptr]
+        if perm is not None:
+            word = perm[word]
+        key = row * K + word
+        del row, t, u, u3, ptr, word, fresh
+        key, _ = torch.sort(key)
+        uk, cnt = torch.unique_consecutive(key, return_counts=True)
+        del key
+        r = torch.div(uk, K, rounding_mode="floor")
+        cols.append((uk - r * K).to(torch.int32))
+        vals.append(cnt.to(torch.int32))
+        lens.append(torch.bincount(r, minlength=n_rows))
+        del uk, cnt, r
+    colidx = torch.cat(cols)
+    v = torch.cat(vals)
+    rl = torch.cat(lens)
+    seen = torch.zeros(K, dtype=torch.bool, device=dev)
+    seen[colidx.to(torch.int64)] = True
+    missing = torch.nonzero(~seen).flatten().to(torch.int32)
+    if missing.numel():
+        colidx = torch.cat([colidx, missing])
+        v = torch.cat([v, torch.ones_like(missing)])
+        rl = torch.cat([rl, torch.ones(missing.numel(), dtype=rl.dtype, device=dev)])
+    rowptr = torch.zeros(rl.numel() + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(rl, 0)
+    return rowptr, colidx.contiguous(), v.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--k", type=int, default=50_000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--solve", action="store_true")
+    ap.add_argument("--no-shuffle", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from bayespy_amd import device as dev
+
+    t0 = time.time()
+    rowptr, colidx, vals = generate(args.rows, args.k, shuffle_columns=not args.no_shuffle)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    N = rowptr.numel() - 1
+    nnz = colidx.numel()
+    max_count = int(vals.max())
+    cs = torch.zeros(nnz + 1, dtype=torch.int64, device=vals.device)
+    cs[1:] = torch.cumsum(vals.to(torch.int64), 0)
+    max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
+    del cs
+    algo = nnz * 8 + (N + 1) * 8
+
+    def one():
+        st = dev.DeviceStats(args.k, max_count, max_total)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st.add_csr(rowptr, colidx, vals, max_count=max_count, max_total=max_total)
+        e1.record()
+        return st, e0, e1
+
+    for _ in range(args.warmup):
+        one()
+    ms = []
+    for _ in range(args.steps):
+        st, e0, e1 = one()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    info = st.check()
+    line = {"workload": "bag-of-words CSR (BASELINE configs[3], one GPU's shard)", "K": args.k,
+            "rows": N, "nnz": nnz, "max_count": max_count, "max_total": max_total,
+            "algorithmic_bytes": algo, "stats_ms": sum(ms) / len(ms), "stats_ms_min": min(ms),
+            "achieved_GBps": algo / (sum(ms) / len(ms) * 1e-3) / 1e9, "gen_seconds": t_gen,
+            "rows_checked": info["rows"]}
+    if args.solve:
+        t0 = time.perf_counter()
+        uv = st.finalize()
+        a0 = st.cli_init_alphas()
+        out = uv.solve(a0, 50, 0.0, trace_alphas=False)
+        line["finalize_solve_ms"] = (time.perf_counter() - t0) * 1e3
+        line["solver"] = {"iterations": out["n_iters"], "loss_evals": out["n_evals"],
+                          "exit": out["exit"], "final_loss": out["final_loss"]}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -80,11 +80,17 @@ int dme_stats_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_
                         void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
 
 /* CSR rows (rowptr int64[N+1], colidx int32[nnz], vals int32[nnz]); same outputs.  Entries with
- * value 0 are legal and ignored, as a zero count is in DE/dme.py:117. */
+ * value 0 are legal and ignored, as a zero count is in DE/dme.py:117.
+ * With a workspace of dme_stats_csr_workspace_bytes(N, nnz, K) bytes (256-byte aligned; it holds
+ * one 8-byte record per stored entry) the pass partitions the entries by column bucket and counts
+ * each bucket in LDS; with workspace == NULL, or for small inputs (the size call returns 0), every
+ * entry costs two 64-bit global atomics instead.  init_acc is summed in arrival order here. */
+int64_t dme_stats_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t K);
 int dme_stats_csr_i32(const int64_t* rowptr /*[dev]*/, const int32_t* colidx /*[dev]*/,
-                      const int32_t* vals /*[dev]*/, int64_t N, int64_t K, uint64_t* hist,
-                      int64_t nbins, uint64_t* histV, int64_t tbins, double* init_acc,
-                      uint64_t* status, void* workspace, int64_t workspace_bytes, void* stream);
+                      const int32_t* vals /*[dev]*/, int64_t N, int64_t nnz, int64_t K,
+                      uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
+                      double* init_acc, uint64_t* status, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse suffix scan: value histograms -> the reference's compressed statistics

@@ -235,3 +235,87 @@ def test_wide_dense_matrix_goes_through_csr(oracle):
         assert info["rows"] == N
         _assert_uv_equal(st.finalize(), ref)
         np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+
+
+def _csr_direct(dev, rowptr, colidx, vals, K, nbins, tbins, partitioned):
+    """dme_stats_csr_i32 through the C ABI with or without the partition workspace."""
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    N, nnz = rowptr.numel() - 1, colidx.numel()
+    hist = torch.zeros(K * nbins, dtype=torch.int64, device="cuda")
+    histV = torch.zeros(tbins, dtype=torch.int64, device="cuda")
+    acc = torch.zeros(K, dtype=torch.float64, device="cuda")
+    status = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ws, wsb, keep = 0, 0, None
+    if partitioned:
+        need = L.dme_stats_csr_workspace_bytes(N, nnz, K)
+        assert need > 0
+        keep = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+        off = (-keep.data_ptr()) % 256
+        ws, wsb = keep.data_ptr() + off, need
+    _lib.check(L.dme_stats_csr_i32(rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), N, nnz, K,
+                                   hist.data_ptr(), nbins, histV.data_ptr(), tbins, acc.data_ptr(),
+                                   status.data_ptr(), ws, wsb, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return hist, histV, acc, status
+
+
+@pytest.mark.parametrize("K", [700, 50_000, 600_000])
+def test_csr_partitioned_equals_atomics_path(K):
+    """The bucket-partitioned CSR pass against the plain atomics kernel on hostile input: empty
+    rows, zero and negative counts, column indices out of range, counts beyond the LDS bins, a hot
+    column, row totals beyond the LDS total bins and beyond tbins, counts beyond nbins."""
+    dev = _dev()
+    rng = np.random.default_rng(K)
+    N = 30_000
+    lens = rng.integers(0, 40, size=N)
+    lens[rng.integers(0, N, size=50)] = 0
+    lens[7] = 3000
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    col = (rng.zipf(1.3, size=nnz) - 1) % K
+    col[rng.random(nnz) < 0.3] = 5                      # hot column
+    val = rng.geometric(0.5, size=nnz)
+    big = rng.random(nnz) < 0.02
+    val[big] = rng.integers(61, 400, size=int(big.sum()))    # beyond BL
+    val[rng.random(nnz) < 0.01] = 0
+    val[rng.integers(0, nnz, size=5)] = -3
+    val[rng.integers(0, nnz, size=5)] = 5000            # >= nbins
+    col[rng.integers(0, nnz, size=5)] = K + 17
+    col[rng.integers(0, nnz, size=5)] = -1
+    nbins, tbins = 450, 20_000                          # row 7 exceeds tbins; others beyond 8192? one:
+    p0 = rowptr[11]
+    if lens[11] > 0:
+        val[p0] = 399
+    rp = torch.from_numpy(rowptr).cuda()
+    ci = torch.from_numpy(col.astype(np.int32)).cuda()
+    vv = torch.from_numpy(val.astype(np.int32)).cuda()
+    a = _csr_direct(dev, rp, ci, vv, K, nbins, tbins, partitioned=False)
+    b = _csr_direct(dev, rp, ci, vv, K, nbins, tbins, partitioned=True)
+    assert torch.equal(a[0], b[0]), "hist"
+    assert torch.equal(a[1], b[1]), "histV"
+    assert torch.equal(a[3], b[3]), (a[3].tolist(), b[3].tolist())
+    st = a[3].tolist()
+    assert st[0] == N and st[1] > 0 and st[3] > 0
+    np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-12, atol=1e-300)
+
+
+def test_csr_partitioned_row_totals_beyond_lds_bins(oracle):
+    """Clean rows with totals up to 30 000 (LDS holds the first 8192 total bins) against the oracle."""
+    dev = _dev()
+    rng = np.random.default_rng(77)
+    N, K = 5000, 3000
+    lens = rng.integers(1, 30, size=N)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    col = np.concatenate([rng.choice(K, size=l, replace=False) for l in lens]).astype(np.int32)
+    val = rng.integers(1, 8, size=nnz).astype(np.int32)
+    heavy = rng.random(nnz) < 0.01
+    val[heavy] = rng.integers(1000, 3000, size=int(heavy.sum()))
+    st = dev.DeviceStats(K)
+    st.add_csr(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda())
+    info = st.check()
+    assert info["rows"] == N and info["max_total"] > 8192
+    ref = oracle.append_rows_csr(rowptr, col, val, K)
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
