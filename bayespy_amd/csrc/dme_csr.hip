@@ -12,9 +12,10 @@
 //                       column bucket (bucket = CB consecutive columns) in LDS        [reads colidx]
 //   csr_offsets_kernel  + csr_bucket_scan_kernel: bucket-major exclusive offsets of every
 //                       (bucket, slab) run
-//   csr_scatter_kernel  wave per row: row total (DPP/shuffle reduction) -> histV in LDS; every entry
-//                       is written as 8 bytes {column-in-bucket | count << cb, row total} to its
-//                       bucket's run                                        [reads all, writes 8 B]
+//   csr_scatter_kernel  batches of whole rows, entry-parallel: row totals by LDS atomics -> histV;
+//                       every entry becomes 8 bytes {column-in-bucket | count << cb, row total},
+//                       ordered by bucket in LDS, written in contiguous pieces to its bucket's
+//                       run                                                 [reads all, writes 8 B]
 //   csr_bucket_kernel   the bucket-major entry stream is cut into equal pieces, one per
 //                       workgroup; a piece holds one bucket (or a few): counts 1..BL of its CB
 //                       columns are privatised in LDS (32-bit), the mean accumulator too (LDS fp64
@@ -27,18 +28,21 @@
 // too small to repay five launches, the atomics kernel runs.
 #include "dme_common.h"
 
-// compile-time ablation for profiling experiments (0 in every shipped build)
-#ifndef DME_CSR_ABLATE
-#define DME_CSR_ABLATE 0
-#endif
-
 namespace {
 
 constexpr int CSR_BLOCK = 1024;
 constexpr int CSR_WAVES = CSR_BLOCK / 64;
 constexpr int CSR_MAX_BUCKETS = 2048;
 constexpr int CSR_HIST_LDS_BYTES = 60 * 1024;
-constexpr int CSR_TBL_MAX = 8192;  // row totals below this are counted in LDS
+constexpr int CSR_TBL_MAX = 2048;  // row totals below this are counted in LDS
+// The scatter kernel runs as many small workgroups (4 waves, ~35 KB of LDS, four per CU): its
+// batches are chains of short dependent LDS phases, and independent workgroups overlap them where
+// one 1024-thread workgroup per CU would sit in barriers.
+constexpr int CSR_SBLOCK = 256;
+constexpr int CSR_SWAVES = CSR_SBLOCK / 64;
+constexpr int CSR_BATCH = 2048;    // entries per batch
+constexpr int CSR_EPT = CSR_BATCH / CSR_SBLOCK;
+constexpr int CSR_RB = CSR_SBLOCK;  // rows per batch at most (one prefetched row pointer per thread)
 constexpr long long CSR_SMALL_NNZ = 1 << 15;
 
 // ---------------------------------------------------------------------------------------------
@@ -92,6 +96,49 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
 // ---------------------------------------------------------------------------------------------
 // partitioned path
 // ---------------------------------------------------------------------------------------------
+// Adds 1 to cnt[b] for every lane with ok set.  Word-frequency data puts most of a wave's lanes in
+// one or two buckets (the head of the vocabulary), and same-address LDS atomics serialise: the
+// bucket of the first pending lane is counted with one atomic for all its lanes, twice, before the
+// remaining lanes go one by one.
+__device__ __forceinline__ void csr_count_lanes(u32* cnt, int b, bool ok) {
+    u64 pending = __ballot(ok);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (!pending) return;
+        const int lead = __builtin_ctzll(pending);
+        const int bl = __shfl(b, lead);
+        const u64 same = __ballot(ok && b == bl) & pending;
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&cnt[bl], (u32)__builtin_popcountll(same));
+        pending &= ~same;
+        if (b == bl) ok = false;
+    }
+    if (ok) atomicAdd(&cnt[b], 1u);
+}
+
+// The same with the rank of every lane returned (its position among the entries of its bucket).
+__device__ __forceinline__ u32 csr_rank_lanes(u32* cnt, int b, bool ok) {
+    u64 pending = __ballot(ok);
+    const u64 below = (1ULL << (threadIdx.x & 63)) - 1;
+    u32 rank = 0;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (!pending) return rank;
+        const int lead = __builtin_ctzll(pending);
+        const int bl = __shfl(b, lead);
+        const u64 same = __ballot(ok && b == bl) & pending;
+        u32 first = 0;
+        if ((int)(threadIdx.x & 63) == lead) first = atomicAdd(&cnt[bl], (u32)__builtin_popcountll(same));
+        first = __shfl(first, lead);
+        if (ok && b == bl) {
+            rank = first + (u32)__builtin_popcountll(same & below);
+            ok = false;
+        }
+        pending &= ~same;
+    }
+    if (ok) rank = atomicAdd(&cnt[b], 1u);
+    return rank;
+}
+
 struct CsrPlan {
     int sh;       // log2(CB)
     int CB;       // columns per bucket
@@ -124,7 +171,7 @@ int plan_csr(long long N, long long nnz, long long K, long long nbins, CsrPlan* 
     p->BL = (int)bl;
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
-    long long G = 2LL * cus;
+    long long G = 4LL * cus;  // all resident at once: four scatter workgroups per CU
     if (G > (N + 63) / 64) G = (N + 63) / 64;
     if (G < 1) G = 1;
     p->G = (int)G;
@@ -173,14 +220,16 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_count_kernel(const long long* r
             const int c1 = __builtin_nontemporal_load(colidx + e + CSR_BLOCK);
             const int c2 = __builtin_nontemporal_load(colidx + e + 2 * CSR_BLOCK);
             const int c3 = __builtin_nontemporal_load(colidx + e + 3 * CSR_BLOCK);
-            if ((u64)(long long)c0 < (u64)K) atomicAdd(&mine[c0 >> sh], 1u);
-            if ((u64)(long long)c1 < (u64)K) atomicAdd(&mine[c1 >> sh], 1u);
-            if ((u64)(long long)c2 < (u64)K) atomicAdd(&mine[c2 >> sh], 1u);
-            if ((u64)(long long)c3 < (u64)K) atomicAdd(&mine[c3 >> sh], 1u);
+            csr_count_lanes(mine, c0 >> sh, (u64)(long long)c0 < (u64)K);
+            csr_count_lanes(mine, c1 >> sh, (u64)(long long)c1 < (u64)K);
+            csr_count_lanes(mine, c2 >> sh, (u64)(long long)c2 < (u64)K);
+            csr_count_lanes(mine, c3 >> sh, (u64)(long long)c3 < (u64)K);
         }
-        for (; e < e1; e += CSR_BLOCK) {
-            const int c = colidx[e];
-            if ((u64)(long long)c < (u64)K) atomicAdd(&mine[c >> sh], 1u);
+        // the tail: whole waves stay in the loop so that the ballots see every lane
+        for (long long eb = e - tid; eb < e1; eb += CSR_BLOCK) {
+            const long long q = eb + tid;
+            const int c = q < e1 ? colidx[q] : -1;
+            csr_count_lanes(mine, c >> sh, q < e1 && (u64)(long long)c < (u64)K);
         }
     }
     __syncthreads();
@@ -262,139 +311,358 @@ struct CsrArgs {
     u64* status;
 };
 
-__global__ __launch_bounds__(CSR_BLOCK) void csr_scatter_kernel(CsrArgs a) {
-    extern __shared__ u64 lds64[];
-    // [NB] run bases (u64) | [NB] cursors (u32) | [TBL] row-total bins (u32) | [8] status
-    u64* base = lds64;
-    u32* cursor = (u32*)(base + a.NB);
-    u32* tb = cursor + a.NB + (a.NB & 1);
-    u64* sh_stat = (u64*)(tb + a.TBL + (a.TBL & 1));
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long g = blockIdx.x;
-    for (int b = tid; b < a.NB; b += CSR_BLOCK) {
-        base[b] = a.start[b] + a.rel[g * a.NB + b];
-        cursor[b] = 0;
+// LDS carve-up of csr_scatter_kernel (bytes), shared with the host for the launch size.
+struct ScatterLds {
+    int off_base, off_rowsum, off_stage, off_rp, off_bcnt, off_boff, off_tb, off_bkt, off_misc, bytes;
+};
+__host__ __device__ inline ScatterLds scatter_lds(int NB, int TBL) {
+    ScatterLds L;
+    int o = 0;
+    auto take = [&](int bytes) {
+        const int at = o;
+        o += (bytes + 15) & ~15;  // every region 16-byte aligned (128-bit LDS accesses)
+        return at;
+    };
+    L.off_base = take(8 * NB);
+    L.off_rowsum = take(8 * CSR_RB);
+    L.off_stage = take(8 * CSR_BATCH);
+    L.off_rp = take(4 * (CSR_RB + 2));
+    L.off_bcnt = take(4 * NB);
+    L.off_boff = take(4 * NB);
+    L.off_tb = take(4 * TBL);
+    L.off_bkt = take(2 * CSR_BATCH);
+    L.off_misc = take(256);
+    L.bytes = o;
+    return L;
+}
+
+// Exclusive scan of n counters (in -> out) by a CSR_SBLOCK-thread workgroup; every thread gets the
+// total.  Thread t owns the consecutive elements [t*per, (t+1)*per).
+__device__ u32 block_excl_scan(const u32* in, u32* out, int n, u32* wsum /*[CSR_SWAVES]*/) {
+    const int tid = threadIdx.x;
+    const int per = (n + CSR_SBLOCK - 1) / CSR_SBLOCK;
+    const int lo = tid * per;
+    int hi = lo + per;
+    if (hi > n) hi = n;
+    u32 s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    u32 inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl_up(inc, d);
+        if ((tid & 63) >= d) inc += o;
     }
-    for (int i = tid; i < a.TBL; i += CSR_BLOCK) tb[i] = 0;
-    if (tid < 8) sh_stat[tid] = 0;
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
+    u32 before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < CSR_SWAVES; ++w) {
+        const u32 t = wsum[w];
+        if (w < (tid >> 6)) before += t;
+        total += t;
+    }
+    u32 run = before + inc - s;
+    for (int i = lo; i < hi; ++i) {
+        const u32 x = in[i];
+        out[i] = run;
+        run += x;
+    }
+    __syncthreads();
+    return total;
+}
+
+// Radix partition of one row slab by column bucket.  The slab is cut into batches of whole rows
+// holding at most CSR_BATCH entries; a batch is loaded entry-parallel (coalesced, CSR_EPT loads in
+// flight per thread, issued one batch ahead), every entry finds its row by binary search over the
+// batch's row pointers (LDS), the row totals are integer LDS atomics, then the entries are ordered
+// by bucket inside LDS and written to their buckets' runs in contiguous pieces (8-byte stores
+// scattered one by one are bound by the L2 request rate).
+__global__ __launch_bounds__(CSR_SBLOCK, 4) void csr_scatter_kernel(CsrArgs a) {
+    extern __shared__ u64 lds64[];
+    char* lds = (char*)lds64;
+    const ScatterLds L = scatter_lds(a.NB, a.TBL);
+    u64* base = (u64*)(lds + L.off_base);      // next global slot of this slab in each bucket
+    u64* rowsum = (u64*)(lds + L.off_rowsum);  // row totals of the batch
+    u64* stage = (u64*)(lds + L.off_stage);    // the batch's records, ordered by bucket
+    u32* rp = (u32*)(lds + L.off_rp);          // row starts relative to the batch start
+    u32* bcnt = (u32*)(lds + L.off_bcnt);
+    u32* boff = (u32*)(lds + L.off_boff);
+    u32* tb = (u32*)(lds + L.off_tb);          // row-total bins below TBL
+    unsigned short* bkt = (unsigned short*)(lds + L.off_bkt);
+    u64* sh_stat = (u64*)(lds + L.off_misc);   // [8]
+    u32* wsum = (u32*)(sh_stat + 8);           // [CSR_SWAVES]
+    int* sh_nr = (int*)(wsum + 16);
+
+    const int tid = threadIdx.x;
+    const long long g = blockIdx.x;
+    for (int b = tid; b < a.NB; b += CSR_SBLOCK) base[b] = a.start[b] + a.rel[g * a.NB + b];
+    for (int i = tid; i < a.TBL; i += CSR_SBLOCK) tb[i] = 0;
+    if (tid < 8) sh_stat[tid] = 0;
     const long long r0 = g * a.rows_per_slab;
     long long r1 = r0 + a.rows_per_slab;
     if (r1 > a.N) r1 = a.N;
+    if (r0 >= r1) return;  // uniform: nothing was written yet
     const u32 cmask = (1u << a.sh) - 1;
     u32 maxv = 0;
-    u64 maxt = 0, bad = 0, big = 0, nrows = 0;
+    u64 maxt = 0, bad = 0, big = 0;
+    // entries of the slab, addressed by 32-bit offsets from a uniform base (the host keeps nnz
+    // below 2^32 on this path)
+    const long long e_slab = a.rowptr[r0];
+    const u32 slab_len = (u32)(a.rowptr[r1] - e_slab);
+    const int* cslab = a.colidx + e_slab;
+    const int* vslab = a.vals + e_slab;
+    __syncthreads();
 
-    // one stored entry: validate, pack, take a slot in its bucket's run, store
-    auto put = [&](long long k, int v, u64 total, u32 n32) {
-        if ((u64)k >= (u64)a.K) {  // not counted by csr_count_kernel either
-            if (v != 0) bad++;
-            return;
+    int c[CSR_EPT], v[CSR_EPT];   // the loaded entries; then {packed record, bucket}
+    u32 n32[CSR_EPT];
+
+    auto fetch_ptr = [&](long long r, int j) -> long long {
+        const long long q = r + j;
+        return q <= r1 ? a.rowptr[q] : 0x7FFFFFFFFFFFFFFFLL;
+    };
+    auto fetch_entries = [&](u32 off) {
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            const u32 q = off + tid + j * CSR_SBLOCK;
+            const bool in = q < slab_len;
+            c[j] = in ? __builtin_nontemporal_load(cslab + q) : 0;
+            v[j] = in ? __builtin_nontemporal_load(vslab + q) : 0;
         }
-        u32 packed = 0;  // count 0: the bucket pass skips it
-        if (v < 0) {
-            bad++;
-        } else if (v > 0) {
-            maxv = (u32)v > maxv ? (u32)v : maxv;
-            if ((long long)v < a.vlim) {
-                packed = ((u32)k & cmask) | ((u32)v << a.sh);
-            } else {
-                if ((long long)v < a.nbins) atomicAdd(&a.hist[k * a.nbins + v], 1ULL);
-                else big++;
-                const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
-                atomicAdd(&a.init_acc[k], __dmul_rn((double)v, w));
+    };
+    // c/v/n32 -> c = packed record, v = bucket (or -1: dropped)
+    auto classify = [&](u32 nb) {
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            const u32 i = tid + j * CSR_SBLOCK;
+            const long long k = c[j];
+            const int x = v[j];
+            c[j] = 0;
+            v[j] = -1;
+            if (i >= nb) continue;
+            if ((u64)k >= (u64)a.K) {  // not counted by csr_count_kernel either
+                if (x != 0) bad++;
+                continue;
             }
+            if (x < 0) {
+                bad++;
+            } else if (x > 0) {
+                maxv = (u32)x > maxv ? (u32)x : maxv;
+                if ((long long)x < a.vlim) {
+                    c[j] = (int)(((u32)k & cmask) | ((u32)x << a.sh));  // count 0: skipped downstream
+                } else {
+                    if ((long long)x < a.nbins) atomicAdd(&a.hist[k * a.nbins + x], 1ULL);
+                    else big++;
+                    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n32[j]));
+                    atomicAdd(&a.init_acc[k], __dmul_rn((double)x, w));
+                }
+            }
+            v[j] = (int)(k >> a.sh);
         }
-        const int b = (int)(k >> a.sh);
-        const u32 slot = (DME_CSR_ABLATE & 16) ? (u32)lane : atomicAdd(&cursor[b], 1u);
-        if (!(DME_CSR_ABLATE & 8)) a.entries[base[b] + slot] = make_uint2(packed, n32);
-        else if (packed == 0xFFFFFFFFu) a.entries[slot] = make_uint2(packed, n32);
+    };
+    // Orders the classified records pk/bk/nn by bucket in LDS and writes them out.  bcnt is zero on
+    // entry and on exit.
+    auto emit = [&](const int* pk, const int* bk, const u32* nn) {
+        u32 rank[CSR_EPT];
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) rank[j] = csr_rank_lanes(bcnt, bk[j], bk[j] >= 0);
+        __syncthreads();
+        const u32 nvalid = block_excl_scan(bcnt, boff, a.NB, wsum);
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            if (bk[j] < 0) continue;
+            const u32 pos = boff[bk[j]] + rank[j];
+            stage[pos] = (u64)(u32)pk[j] | ((u64)nn[j] << 32);
+            bkt[pos] = (unsigned short)bk[j];
+        }
+        __syncthreads();
+        u64* out = (u64*)a.entries;
+        for (u32 i = tid; i < nvalid; i += CSR_SBLOCK) {
+            const int b = bkt[i];
+            out[base[b] + (i - boff[b])] = stage[i];
+        }
+        __syncthreads();
+        for (int b = tid; b < a.NB; b += CSR_SBLOCK) {
+            base[b] += bcnt[b];
+            bcnt[b] = 0;
+        }
+        __syncthreads();
+    };
+    // One row's total -> histV (LDS bins below TBL), maxima, the rows-beyond-tbins counter.
+    auto count_total = [&](u64 t) {
+        if (t == 0) return;
+        maxt = t > maxt ? t : maxt;
+        if (t < (u64)a.TBL) atomicAdd(&tb[t], 1u);
+        else if ((long long)t < a.tbins) atomicAdd(&a.histV[t], 1ULL);
+        else atomicAdd(&sh_stat[2], 1ULL);
     };
 
-    // Each wave takes R consecutive rows per trip, and the trips are software-pipelined: while trip
-    // t is processed, the entries of trip t+1 and the row pointers of trip t+2 are in flight.
-    // With one row at a time the pass is bound by the rowptr -> entries -> store latency chain.
-    constexpr int R = 4;
-    const long long stride = (long long)CSR_WAVES * R;
-    auto load_ptrs = [&](long long r) -> long long {  // rowptr[r .. r+R] on lanes 0..R
-        long long rr = r + lane;
-        if (rr > r1) rr = r1;
-        return (lane <= R && r < r1) ? a.rowptr[rr] : 0;
-    };
-    long long r = r0 + (long long)wave * R;
-    long long pl_nxt = load_ptrs(r);
-    long long pl_n2 = load_ptrs(r + stride);
-    long long p[R + 1];
-    int c[R], v[R];
-#pragma unroll
-    for (int j = 0; j <= R; ++j) p[j] = __shfl(pl_nxt, j);
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const long long q = p[j] + lane;
-        const bool in = q < p[j + 1];
-        c[j] = in ? __builtin_nontemporal_load(a.colidx + q) : 0;
-        v[j] = in ? __builtin_nontemporal_load(a.vals + q) : 0;
-    }
-    pl_nxt = pl_n2;
-    for (; r < r1; r += stride) {
-        pl_n2 = load_ptrs(r + 2 * stride);
-        long long pn[R + 1];
-        int cn[R], vn[R];
-#pragma unroll
-        for (int j = 0; j <= R; ++j) pn[j] = __shfl(pl_nxt, j);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const long long q = pn[j] + lane;
-            const bool in = q < pn[j + 1];
-            cn[j] = in ? __builtin_nontemporal_load(a.colidx + q) : 0;
-            vn[j] = in ? __builtin_nontemporal_load(a.vals + q) : 0;
-        }
-        u64 total[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            u64 sacc = (u64)(v[j] > 0 ? v[j] : 0);
-            for (long long q = p[j] + 64 + lane; q < p[j + 1]; q += 64) {  // rows beyond 64 entries
-                const int x = a.vals[q];
-                sacc += (u64)(x > 0 ? x : 0);
+    for (int b = tid; b < a.NB; b += CSR_SBLOCK) bcnt[b] = 0;
+    long long r = r0;
+    u32 off = 0;  // the batch starts at entry e_slab + off
+    long long pre0 = fetch_ptr(r, tid), pre1 = tid == 0 ? fetch_ptr(r, CSR_SBLOCK) : 0;
+    fetch_entries(0);
+    while (r < r1) {
+        const int nrw = (int)(r1 - r < CSR_RB ? r1 - r : CSR_RB);
+        {
+            const long long e0 = e_slab + off;
+            const long long d = pre0 - e0;
+            rp[tid] = d > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (u32)d;
+            if (tid == 0) {
+                const long long d1 = pre1 - e0;
+                rp[CSR_SBLOCK] = d1 > 0xFFFFFFFFLL ? 0xFFFFFFFFu : (u32)d1;
             }
-            if (sacc > 0xFFFFFFFFFFFFULL) sacc = 0xFFFFFFFFFFFFULL;
-            total[j] = (u64)dme_wave_sum_u32((u32)(sacc & 0xFFFFFF)) +
-                       ((u64)dme_wave_sum_u32((u32)(sacc >> 24)) << 24);
         }
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (r + j >= r1) break;
-            const u64 t = total[j];
-            nrows++;
-            if (lane == 0 && t > 0) {
-                maxt = t > maxt ? t : maxt;
-                if (t < (u64)a.TBL) atomicAdd(&tb[t], 1u);
-                else if ((long long)t < a.tbins) atomicAdd(&a.histV[t], 1ULL);
-                else atomicAdd(&sh_stat[2], 1ULL);
+        __syncthreads();
+        if (tid <= nrw && rp[tid] <= (u32)CSR_BATCH && (tid == nrw || rp[tid + 1] > (u32)CSR_BATCH))
+            *sh_nr = tid;
+        if (tid == 0 && nrw == CSR_RB && rp[CSR_RB] <= (u32)CSR_BATCH) *sh_nr = CSR_RB;
+        __syncthreads();
+        const int nr = *sh_nr;
+        if (nr == 0) {
+            // the row alone holds more than a batch: total by a workgroup reduction, then its
+            // entries in batch-sized chunks (not pipelined)
+            const u32 len = rp[1];
+            if (tid == 0) rowsum[0] = 0;
+            __syncthreads();
+            u64 part = 0;
+            for (u32 q = tid; q < len; q += CSR_SBLOCK) {
+                const int x = vslab[off + q];
+                part += (u64)(x > 0 ? x : 0);
             }
-            const u32 n32 = t > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (u32)t;
-            if (p[j] + lane < p[j + 1]) put(c[j], v[j], t, n32);
-            for (long long q = p[j] + 64 + lane; q < p[j + 1]; q += 64)
-                put(a.colidx[q], a.vals[q], t, n32);
-        }
+            part = dme_wave_sum_u64(part);
+            if ((tid & 63) == 0 && part) atomicAdd(&rowsum[0], part);
+            __syncthreads();
+            const u64 t = rowsum[0];
+            if (tid == 0) count_total(t);
+            const u32 tn = t > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (u32)t;
+            for (u32 q0 = 0; q0 < len; q0 += CSR_BATCH) {
+                const u32 nb = len - q0 < (u32)CSR_BATCH ? len - q0 : (u32)CSR_BATCH;
+                fetch_entries(off + q0);
 #pragma unroll
-        for (int j = 0; j <= R; ++j) p[j] = pn[j];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            c[j] = cn[j];
-            v[j] = vn[j];
+                for (int j = 0; j < CSR_EPT; ++j) n32[j] = tn;
+                classify(nb);
+                emit(c, v, n32);
+            }
+            r += 1;
+            off += len;
+            pre0 = fetch_ptr(r, tid);
+            pre1 = tid == 0 ? fetch_ptr(r, CSR_SBLOCK) : 0;
+            fetch_entries(off);
+            continue;
         }
-        pl_nxt = pl_n2;
+        const u32 nb = rp[nr];
+        // the next batch's row pointers go out now; they are needed one trip later
+        pre0 = fetch_ptr(r + nr, tid);
+        pre1 = tid == 0 ? fetch_ptr(r + nr, CSR_SBLOCK) : 0;
+        // Row totals and the row of every entry from two inclusive prefix sums over the batch (entry
+        // order): S over the counts (stage area), total(t) = S[rp[t+1]-1] - S[rp[t]-1]; and C over
+        // the number of rows starting at each position (16-bit, in the bkt area), row(i) = C[i].
+        // Adding each entry to its row's sum with LDS atomics serialises (a wave's 64 consecutive
+        // entries share one or two rows), and a binary search per entry costs ~50 VALU operations.
+        u32* cntw = (u32*)bkt;  // two 16-bit counters per word
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            const u32 i = tid + j * CSR_SBLOCK;
+            stage[i] = (i < nb && v[j] > 0) ? (u64)v[j] : 0;
+        }
+        for (int i = tid; i < CSR_BATCH / 2; i += CSR_SBLOCK) cntw[i] = 0;
+        __syncthreads();
+        if (tid >= 1 && tid < nr) {
+            const u32 q = rp[tid];
+            if (q < nb) atomicAdd(&cntw[q >> 1], (q & 1) ? 0x10000u : 1u);
+        }
+        __syncthreads();
+        {
+            u64 x[CSR_EPT];
+            u64 sum = 0;
+            u32 cs[CSR_EPT];
+            u32 csum = 0;
+            const uint4 cw = *(const uint4*)(cntw + tid * (CSR_EPT / 2));  // CSR_EPT == 8
+            const u32 cwv[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+            for (int j = 0; j < CSR_EPT; ++j) {
+                sum += stage[tid * CSR_EPT + j];
+                x[j] = sum;
+                csum += (cwv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                cs[j] = csum;
+            }
+            u64 inc = sum;
+            u32 cinc = csum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const u64 o = __shfl_up(inc, d);
+                const u32 oc = __shfl_up(cinc, d);
+                if ((tid & 63) >= d) {
+                    inc += o;
+                    cinc += oc;
+                }
+            }
+            u64* wtot = (u64*)(sh_nr + 2);  // [CSR_SWAVES], 8-byte aligned behind sh_nr
+            u32* wcnt = (u32*)(wtot + CSR_SWAVES);
+            if ((tid & 63) == 63) {
+                wtot[tid >> 6] = inc;
+                wcnt[tid >> 6] = cinc;
+            }
+            __syncthreads();
+            u64 before = inc - sum;
+            u32 cbefore = cinc - csum;
+#pragma unroll
+            for (int w = 0; w < CSR_SWAVES; ++w)
+                if (w < (tid >> 6)) {
+                    before += wtot[w];
+                    cbefore += wcnt[w];
+                }
+#pragma unroll
+            for (int j = 0; j < CSR_EPT; ++j) stage[tid * CSR_EPT + j] = before + x[j];
+            uint4 outw;
+            outw.x = (cbefore + cs[0]) | ((cbefore + cs[1]) << 16);
+            outw.y = (cbefore + cs[2]) | ((cbefore + cs[3]) << 16);
+            outw.z = (cbefore + cs[4]) | ((cbefore + cs[5]) << 16);
+            outw.w = (cbefore + cs[6]) | ((cbefore + cs[7]) << 16);
+            *(uint4*)(cntw + tid * (CSR_EPT / 2)) = outw;
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const u32 lo = rp[tid], hi = rp[tid + 1];
+            const u64 t = (hi ? stage[hi - 1] : 0) - (lo ? stage[lo - 1] : 0);
+            rowsum[tid] = t;
+            count_total(t);
+        }
+        int row[CSR_EPT];
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            const u32 i = tid + j * CSR_SBLOCK;
+            row[j] = i < nb ? bkt[i] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            const u64 t = rowsum[row[j]];
+            n32[j] = t > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (u32)t;
+        }
+        classify(nb);
+        // the records move to their own registers; c/v take the next batch's loads, which then
+        // overlap the ordering and the write-out below
+        int pk[CSR_EPT], bk[CSR_EPT];
+#pragma unroll
+        for (int j = 0; j < CSR_EPT; ++j) {
+            pk[j] = c[j];
+            bk[j] = v[j];
+        }
+        off += nb;
+        fetch_entries(off);
+        emit(pk, bk, n32);  // its barriers also order the rowsum reads before the next zeroing
+        r += nr;
     }
+    if (tid == 0) sh_stat[0] = (u64)(r1 - r0);
     if (bad) atomicAdd(&sh_stat[3], bad);
     if (big) atomicAdd(&sh_stat[1], big);
     if (maxv) atomicMax(&sh_stat[4], (u64)maxv);
     if (maxt) atomicMax(&sh_stat[5], maxt);
-    if (lane == 0 && nrows) atomicAdd(&sh_stat[0], nrows);
     __syncthreads();
-    for (int i = tid; i < a.TBL; i += CSR_BLOCK) {
-        const u32 c = tb[i];
-        if (c) atomicAdd(&a.histV[i], (u64)c);
+    for (int i = tid; i < a.TBL; i += CSR_SBLOCK) {
+        const u32 cn = tb[i];
+        if (cn) atomicAdd(&a.histV[i], (u64)cn);
     }
     if (tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
@@ -454,21 +722,12 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_bucket_kernel(BucketArgs a) {
                 const u32 ex = (u32)raw, ey = (u32)(raw >> 32);
                 const u32 v = ex >> a.sh;
                 if (v == 0) return;
-                const u32 cl = (DME_CSR_ABLATE & 128) ? ((ex + (u32)tid) & cmask) : (ex & cmask);
-                if (!(DME_CSR_ABLATE & 1)) {
-                    if (v <= (u32)a.BL) atomicAdd(&h[cl * a.BL + (v - 1)], 1u);
-                    else atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], 1ULL);
-                }
-                const double w = (DME_CSR_ABLATE & 4) ? (double)ey
-                                                      : __ddiv_rn(1.0, __dadd_rn(1.0, (double)ey));
-                if (DME_CSR_ABLATE & 256)
-                    atomicAdd((u64*)&acc[(ey & acmask) * CB + cl], (u64)(__dmul_rn((double)v, w) * 1e12));
-                else if (DME_CSR_ABLATE & 512)
-                    atomicAdd((float*)&acc[(ey & acmask) * CB + cl], (float)__dmul_rn((double)v, w));
-                else if (!(DME_CSR_ABLATE & 2))
-                    __hip_atomic_fetch_add(&acc[(ey & acmask) * CB + cl], __dmul_rn((double)v, w),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else if (w == 12345.0) acc[cl] = w;
+                const u32 cl = ex & cmask;
+                if (v <= (u32)a.BL) atomicAdd(&h[cl * a.BL + (v - 1)], 1u);
+                else atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], 1ULL);
+                const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)ey));
+                __hip_atomic_fetch_add(&acc[(ey & acmask) * CB + cl], __dmul_rn((double)v, w),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             const u64* src = (const u64*)a.entries;
             u64 e = pos + tid;
@@ -515,29 +774,41 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_reduce_kernel(BucketArgs a) {
     const int i = blockIdx.y * CSR_BLOCK + tid;
     if (i < cells) {
         u64 sum = 0;
-        for (int w = w_lo; w <= w_hi; ++w)
-            sum += ((const u32*)(a.images + (long long)(b + w) * a.image_bytes + 8LL * a.AC * CB))[i];
+        const char* img = a.images + 8LL * a.AC * CB + 4LL * i;
+        int w = w_lo;
+        for (; w + 7 <= w_hi; w += 8) {  // eight loads in flight: a Zipf head bucket has hundreds of runs
+            u32 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = *(const u32*)(img + (long long)(b + w + q) * a.image_bytes);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += x[q];
+        }
+        for (; w <= w_hi; ++w) sum += *(const u32*)(img + (long long)(b + w) * a.image_bytes);
         if (sum) {
             const int cl = i / a.BL, bin = i - cl * a.BL + 1;
             a.hist[(kbase + cl) * a.nbins + bin] += sum;
         }
     }
-    if (blockIdx.y == 0) {
-        for (int c = tid; c < CB; c += CSR_BLOCK) {
-            double sum = 0.0;
-            for (int w = w_lo; w <= w_hi; ++w) {
-                const double* img = (const double*)(a.images + (long long)(b + w) * a.image_bytes);
-                for (int q = 0; q < a.AC; ++q) sum = __dadd_rn(sum, img[q * CB + c]);
-            }
-            if (sum != 0.0) a.init_acc[kbase + c] = __dadd_rn(a.init_acc[kbase + c], sum);
+    // the fp64 accumulators: block y takes the runs w = w_lo + y, + gridDim.y, ... (a Zipf head bucket
+    // has hundreds of runs) and adds its partial sum with one atomic per column
+    for (int c = tid; c < CB; c += CSR_BLOCK) {
+        double sum = 0.0;
+        for (int w = w_lo + (int)blockIdx.y; w <= w_hi; w += (int)gridDim.y) {
+            const double* img = (const double*)(a.images + (long long)(b + w) * a.image_bytes);
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = q < a.AC ? img[q * CB + c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum = __dadd_rn(sum, x[q]);
         }
+        if (sum != 0.0) atomicAdd(&a.init_acc[kbase + c], sum);
     }
 }
 
 }  // namespace
 
 extern "C" int64_t dme_stats_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t K) {
-    if (N <= 0 || K <= 0 || nnz < CSR_SMALL_NNZ) return 0;
+    if (N <= 0 || K <= 0 || nnz < CSR_SMALL_NNZ || nnz >= (1LL << 32)) return 0;
     CsrPlan p;
     if (plan_csr(N, nnz, K, 2, &p) != DME_OK) return 0;
     return p.bytes;
@@ -556,7 +827,8 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     hipStream_t s = (hipStream_t)stream;
 
     CsrPlan p;
-    bool partitioned = workspace != nullptr && nnz >= CSR_SMALL_NNZ;
+    // the scatter kernel addresses a slab's entries with 32-bit offsets
+    bool partitioned = workspace != nullptr && nnz >= CSR_SMALL_NNZ && nnz < (1LL << 32);
     if (partitioned) {
         if (plan_csr(N, nnz, K, nbins, &p) != DME_OK) partitioned = false;  // K beyond the buckets
         else
@@ -602,10 +874,10 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     a.TBL = (int)(tbins < CSR_TBL_MAX ? tbins : CSR_TBL_MAX);
     a.rel = rel; a.start = start; a.entries = entries;
     a.hist = (u64*)hist; a.histV = (u64*)histV; a.init_acc = init_acc; a.status = (u64*)status;
-    const size_t lds_scatter = 8 * (size_t)p.NB + 4 * (size_t)(p.NB + (p.NB & 1)) +
-                               4 * (size_t)(a.TBL + (a.TBL & 1)) + 64;
-    if (!(DME_CSR_ABLATE & 64))
-        hipLaunchKernelGGL(csr_scatter_kernel, dim3(p.G), dim3(CSR_BLOCK), lds_scatter, s, a);
+    const size_t lds_scatter = (size_t)scatter_lds(p.NB, a.TBL).bytes;
+    DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr_scatter_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(csr_scatter_kernel, dim3(p.G), dim3(CSR_SBLOCK), lds_scatter, s, a);
 
     BucketArgs bk{};
     bk.entries = entries; bk.start = start; bk.K = K; bk.nbins = nbins;
@@ -616,8 +888,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     bk.image_bytes = (long long)lds_bucket;
     DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr_bucket_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    if (!(DME_CSR_ABLATE & 32))
-        hipLaunchKernelGGL(csr_bucket_kernel, dim3(p.W), dim3(CSR_BLOCK), lds_bucket, s, bk);
+    hipLaunchKernelGGL(csr_bucket_kernel, dim3(p.W), dim3(CSR_BLOCK), lds_bucket, s, bk);
     hipLaunchKernelGGL(csr_reduce_kernel, dim3(p.NB, (p.CB * p.BL + CSR_BLOCK - 1) / CSR_BLOCK),
                        dim3(CSR_BLOCK), 0, s, bk);
     DME_HIP_CHECK(hipGetLastError());
