@@ -441,6 +441,43 @@ class DeviceStats:
         self.status[4:6] = mx
         return self
 
+    # -- persistence: statistics of row sets computed at different times or places add up -----------
+    def save(self, path):
+        """Writes the statistics as a .npz file (the histograms' non-zero cells, the row-total
+        histogram, the mean accumulator, the status words).  The reference keeps U/V in memory
+        only; files written here can be loaded and merged (`load`, `merge_`) in any order, which
+        gives incremental estimation over data that arrives in pieces."""
+        self.check()
+        h = self.hist.view(self.K, self.nbins)
+        nz = torch.nonzero(h)
+        np.savez(path, format=np.array([1]), K=np.array([self.K]),
+                 nbins=np.array([self.nbins]), tbins=np.array([self.tbins]),
+                 cols=nz[:, 0].to(torch.int32).cpu().numpy(),
+                 bins=nz[:, 1].to(torch.int32).cpu().numpy(),
+                 counts=h[nz[:, 0], nz[:, 1]].cpu().numpy(),
+                 histV=self.histV.cpu().numpy(), init_acc=self.init_acc.cpu().numpy(),
+                 status=self.status.cpu().numpy())
+
+    @classmethod
+    def load(cls, path, device=None):
+        with np.load(path, allow_pickle=False) as f:
+            if int(f["format"][0]) != 1:
+                raise ValueError("unknown statistics file format")
+            K, nbins, tbins = int(f["K"][0]), int(f["nbins"][0]), int(f["tbins"][0])
+            st = cls(K, nbins - 1, tbins - 1, device=device)
+            st.reserve(nbins - 1, tbins - 1)
+            dev = st.device
+            cols = torch.from_numpy(f["cols"].astype(np.int64)).to(dev)
+            bins = torch.from_numpy(f["bins"].astype(np.int64)).to(dev)
+            if cols.numel() and (int(cols.max()) >= K or int(bins.max()) >= st.nbins
+                                 or int(cols.min()) < 0 or int(bins.min()) < 0):
+                raise ValueError("statistics file: cell index out of range")
+            st.hist.view(K, st.nbins)[cols, bins] = torch.from_numpy(f["counts"].astype(np.int64)).to(dev)
+            st.histV[:tbins] = torch.from_numpy(f["histV"].astype(np.int64)).to(dev)
+            st.init_acc.copy_(torch.from_numpy(f["init_acc"].astype(np.float64)).to(dev))
+            st.status.copy_(torch.from_numpy(f["status"].astype(np.int64)).to(dev))
+        return st
+
     # -- scan -------------------------------------------------------------------------------------
     def finalize(self):
         """Reverse suffix scan -> DeviceUV (the reference's U/V, exact integers + fp64 copies)."""

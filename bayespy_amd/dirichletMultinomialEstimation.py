@@ -170,6 +170,31 @@ class CompressedRowData:
             self._lists = self._device_uv().to_lists()
         return self._lists
 
+    # -- persistence and merging (no reference counterpart: its U/V live in memory only) ----------
+    def saveStatistics(self, path):
+        """Writes the integer statistics of the rows appended so far (DeviceStats.save)."""
+        if self._wpending or self._wstats is not None:
+            raise NotImplementedError("weighted rows are not part of the statistics file")
+        self.deviceStats().save(path)
+
+    @classmethod
+    def loadStatistics(cls, path, device=None):
+        st = _dev.DeviceStats.load(path, device=device)
+        obj = cls(st.K, device=device)
+        obj._stats = st
+        return obj
+
+    def merge(self, other):
+        """Adds the rows counted in `other` (same K): statistics of disjoint row sets add exactly."""
+        if other.K != self.K:
+            raise ValueError("K differs")
+        if other._wpending or other._wstats is not None:
+            raise NotImplementedError("merging weighted rows")
+        self.deviceStats().merge_(other.deviceStats())
+        self._uv = None
+        self._lists = None
+        return self
+
     def deviceStats(self):
         """The underlying DeviceStats (histograms, init accumulator), rows flushed."""
         self._flush()

@@ -188,3 +188,28 @@ def test_weighted_rows_match_reference():
     out = DME.findDirichletPriors(obj, fx["init"], 50)
     np.testing.assert_allclose(out, fx["final"], rtol=1e-9)
     np.testing.assert_allclose(DME.getTotalLoss(out, obj), fx["final_loss"], rtol=1e-12)
+
+
+def test_statistics_files_merge_to_the_whole(tmp_path):
+    """Statistics of two halves saved to disk, loaded and merged = statistics of all rows; the
+    solve from the merged object equals the solve from the whole."""
+    from bayespy_amd import dirichletMultinomialEstimation as DME
+    fx = load_golden("dirmult_k50")
+    X = fx["X"].astype(np.int32)
+    h = X.shape[0] // 2
+    parts = []
+    for i, blk in enumerate((X[:h], X[h:])):
+        d = DME.CompressedRowData(fx["K"])
+        d.appendMatrix(blk)
+        p = str(tmp_path / f"part{i}.npz")
+        d.saveStatistics(p)
+        parts.append(p)
+    merged = DME.CompressedRowData.loadStatistics(parts[0]).merge(DME.CompressedRowData.loadStatistics(parts[1]))
+    assert merged.U == fx["U"] and merged.V == fx["V"]
+    st = merged.deviceStats()
+    assert st.check()["rows"] == X.shape[0]
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), fx["init_acc"], rtol=1e-13)
+    whole = DME.CompressedRowData(fx["K"])
+    whole.appendMatrix(X)
+    a0 = st.cli_init_alphas().cpu().numpy().tolist()
+    assert DME.findDirichletPriors(merged, a0, 50) == DME.findDirichletPriors(whole, a0, 50)
