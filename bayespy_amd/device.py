@@ -417,15 +417,16 @@ class DeviceStats:
         return int(self.status[0].cpu())
 
     # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
-    def allreduce(self, group=None):
-        """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs).  One MAX reduce
-        agrees the histogram extents, then one integer SUM over hist || histV || status and one
-        fp64 SUM over the K mean accumulators.  After it every rank holds the global statistics
-        and solves redundantly; there is no per-iteration communication."""
+    def allreduce(self, group=None, same_extents=False):
+        """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs): one integer SUM
+        all-reduce, see parallel.allreduce_stats_tensors.  `same_extents=True` when every rank
+        passed the same max_count / max_total (no extent agreement round, no host sync).  After
+        it every rank holds the global statistics and solves redundantly; there is no
+        per-iteration communication."""
         from .parallel import allreduce_stats_tensors
         (self.hist, self.histV, self.status, self.init_acc, self.nbins,
          self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
-                                               self.K, self.nbins, self.tbins, group)
+                                               self.K, self.nbins, self.tbins, group, same_extents)
         return self
 
     def merge_(self, other):

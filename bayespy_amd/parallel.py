@@ -3,10 +3,11 @@ xGMI on MI355X; "gloo" in CPU tests).
 
 The statistics are sums of per-row indicator terms (DirichletEstimation/
 dirichletMultinomialEstimation.py:116-123), so histograms built from disjoint row shards add
-exactly in integers.  Communication per estimation: one MAX all-reduce of the two histogram
-extents, one integer SUM all-reduce of hist || histV || status, one MAX of the two observed
-maxima and one fp64 SUM of the K mean accumulators.  The suffix scan runs after the reduce and
-the Newton loop is replicated on every rank — no per-iteration communication.
+exactly in integers.  Communication per estimation: ONE integer SUM all-reduce (histograms, status
+words, and per-rank slots that transport the maxima and the fp64 mean accumulators unchanged),
+preceded by one MAX all-reduce of the two histogram extents unless the ranks already agree on
+them.  The suffix scan runs after the reduce and the Newton loop is replicated on every rank —
+no per-iteration communication.
 """
 import torch
 
@@ -35,27 +36,47 @@ def grow_vec(v, new_len):
     return new
 
 
-def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None):
-    """All-reduces one rank's partial statistics in place of a per-rank copy.  Tensors may live
-    on any device the process group supports.  Returns (hist, histV, status, init_acc, nbins,
-    tbins) holding the global statistics on every rank."""
+def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
+                            same_extents=False):
+    """All-reduces one rank's partial statistics.  Tensors may live on any device the process
+    group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
+    statistics on every rank.
+
+    One integer SUM carries everything: hist || histV || the four additive status words || one
+    slot per rank for its two observed maxima || one slot per rank for the bit patterns of its K
+    mean accumulators.  A rank fills only its own slots, so the sum hands every rank all the
+    per-rank values unchanged; the maxima are then taken locally and the fp64 accumulators are
+    added in rank order, which makes the start point of the replicated solve identical on every
+    rank and from run to run.  `same_extents` (every rank built its histograms with the same
+    max_count / max_total) skips the MAX all-reduce that otherwise agrees the extents first."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return hist, histV, status, init_acc, nbins, tbins
-    ext = torch.tensor([nbins, tbins], dtype=torch.int64, device=hist.device)
-    dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
-    nb, tb = (int(v) for v in ext.cpu())
-    hist = grow_hist(hist, K, nbins, nb)
-    histV = grow_vec(histV, tb)
-    mx = status[4:6].clone()
-    flat = torch.cat([hist, histV, status])
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nb, tb = nbins, tbins
+    if not same_extents:
+        ext = torch.tensor([nbins, tbins], dtype=torch.int64, device=hist.device)
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
+        nb, tb = (int(v) for v in ext.cpu())
+        hist = grow_hist(hist, K, nbins, nb)
+        histV = grow_vec(histV, tb)
+    slots = torch.zeros(world, 2 + K, dtype=torch.int64, device=hist.device)
+    slots[rank, :2] = status[4:6]
+    slots[rank, 2:] = init_acc.view(torch.int64)
+    flat = torch.cat([hist, histV, status[:4], slots.view(-1)])
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor
+        # was seen to hang when issued behind a long-running kernel of the same process; RCCL
+        # ("nccl") orders itself on the stream and needs no host sync
+        torch.cuda.current_stream(flat.device).synchronize()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
-    init_acc = init_acc.clone()
-    dist.all_reduce(init_acc, op=dist.ReduceOp.SUM, group=group)
     nh, nv = hist.numel(), histV.numel()
-    hist = flat[:nh].clone()
-    histV = flat[nh:nh + nv].clone()
-    status = flat[nh + nv:].clone()
-    status[4:6] = mx
-    return hist, histV, status, init_acc, nb, tb
+    slots = flat[nh + nv + 4:].view(world, 2 + K)
+    out_status = torch.zeros_like(status)
+    out_status[:4] = flat[nh + nv:nh + nv + 4]
+    out_status[4:6] = slots[:, :2].max(dim=0).values
+    parts = slots[:, 2:].contiguous().view(torch.float64)
+    acc = parts[0].clone()
+    for r in range(1, world):  # fixed order: bit-identical on every rank
+        acc += parts[r]
+    return flat[:nh], flat[nh:nh + nv], out_status, acc, nb, tb

@@ -55,6 +55,9 @@ def parse():
 
 def main():
     args = parse()
+    if os.environ.get("DME_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DME_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
 
@@ -100,7 +103,7 @@ def main():
         st.add_dense(X, max_count=M, max_total=M)
         if timers is not None:
             e1.record()
-        st.allreduce()
+        st.allreduce(same_extents=True)  # every rank sized its histograms for the same M
         uv = st.finalize()
         a0 = st.cli_init_alphas()
         st.check_async()  # status words travel to pinned memory behind the scan

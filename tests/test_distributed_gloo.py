@@ -32,7 +32,7 @@ def _hist_of(X, K):
     return hist, histV, status, acc, nb, tb
 
 
-def _worker(rank, world, port, X, K, out):
+def _worker(rank, world, port, X, K, out, same_extents=False):
     sys.path.insert(0, ROOT)
     from bayespy_amd.parallel import allreduce_stats_tensors, shard_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -40,8 +40,14 @@ def _worker(rank, world, port, X, K, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_rows(X.shape[0], rank, world)
     hist, histV, status, acc, nb, tb = _hist_of(X[lo:hi], K)
+    if same_extents:  # every rank sizes its histograms for the same stated bounds
+        from bayespy_amd.parallel import grow_hist, grow_vec
+        hist = grow_hist(torch.from_numpy(hist.reshape(-1)), K, nb, 64).numpy()
+        histV = grow_vec(torch.from_numpy(histV), 512).numpy()
+        nb, tb = 64, 512
     res = allreduce_stats_tensors(torch.from_numpy(hist.reshape(-1)), torch.from_numpy(histV),
-                                  torch.from_numpy(status), torch.from_numpy(acc), K, nb, tb)
+                                  torch.from_numpy(status), torch.from_numpy(acc), K, nb, tb,
+                                  same_extents=same_extents)
     h, v, st, a, nb2, tb2 = res
     out[rank] = (h.view(K, nb2).numpy().copy(), v.numpy().copy(), st.numpy().copy(),
                  a.numpy().copy(), nb2, tb2)
@@ -72,6 +78,7 @@ def test_allreduce_of_shard_histograms_is_exact(world):
         assert np.array_equal(h, hist) and np.array_equal(v, histV)
         assert st[0] == N and st[4] == 40 and st[5] == status[5]
         np.testing.assert_allclose(a, acc, rtol=1e-13)
+        assert np.array_equal(a, out[0][3])  # summed in rank order: the same bits on every rank
     # and the suffix scan of the reduced histograms is the reference's U/V
     sys.path.insert(0, ROOT)
     import oracle
@@ -81,3 +88,22 @@ def test_allreduce_of_shard_histograms_is_exact(world):
         assert U_k[:len(ref.U[k])].tolist() == ref.U[k].tolist() and not U_k[len(ref.U[k]):].any()
     V = np.cumsum(histV[::-1])[::-1][1:]
     assert V[:len(ref.V)].tolist() == ref.V.tolist()
+
+
+def test_allreduce_with_agreed_extents_is_one_collective():
+    """same_extents=True: no extent round; results as above on histograms padded to the bounds."""
+    rng = np.random.default_rng(12)
+    K, N, world = 5, 300, 2
+    X = rng.integers(0, 9, size=(N, K)) * (rng.random((N, K)) < 0.5)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), X, K, out, True), nprocs=world, join=True)
+    hist, histV, status, acc, nb, tb = _hist_of(X, K)
+    for r in range(world):
+        h, v, st, a, nb2, tb2 = out[r]
+        assert (nb2, tb2) == (64, 512)
+        assert np.array_equal(h[:, :nb], hist) and not h[:, nb:].any()
+        assert np.array_equal(v[:tb], histV) and not v[tb:].any()
+        assert st[0] == N and st[4] == status[4] and st[5] == status[5]
+        np.testing.assert_allclose(a, acc, rtol=1e-13)
+        assert np.array_equal(a, out[0][3])
