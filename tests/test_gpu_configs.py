@@ -48,7 +48,7 @@ def test_config5_heavy_tail(oracle):
     """C5: K=100, row totals min(floor(5*(Pareto(1.2)+1)), 1e5), int32 dense; stresses lenV=1e5,
     ragged U, the global-atomic spill path and multi-segment columns in the solver."""
     from bayespy_amd import device
-    N, K = 300_000, 100
+    N, K = 1_000_000, 100
     rng = np.random.default_rng(20260005)
     alpha_true = 0.05 + rng.gamma(2.0, 0.3, size=K)
     g = torch.Generator(device="cuda").manual_seed(5)

@@ -187,18 +187,20 @@ def test_csr_matches_dense(oracle):
 
 
 def test_large_synthetic_properties():
-    """Size-independent checks at a size the oracle cannot reach (2M x 1000 uint16 = 4 GB):
+    """Size-independent checks at BASELINE's full size (configs[2]: 10M x 1000 uint16 = 20 GB), which
+    the oracle cannot reach:
     sum_n U[k][n] = column sum, sum_n V[n] = grand total, V[0] = #non-empty rows,
     U non-increasing, and two half-passes add up to the full pass."""
     dev = _dev()
-    K, N = 1000, 2_000_000
+    K, N = 1000, 10_000_000
     rng = np.random.default_rng(0)
     alpha = 0.01 + rng.gamma(2.0, 0.05, size=K)
     totals = torch.randint(1, 501, (N,), dtype=torch.int32, device="cuda",
                            generator=torch.Generator(device="cuda").manual_seed(1))
     X = dev.synth_dirmult(N, K, alpha, totals, seed=20260003)
-    rowsum = X.view(torch.int16).to(torch.int32).bitwise_and(0xFFFF).sum(dim=1)
-    assert torch.equal(rowsum, totals)  # the generator itself: every row has its total
+    for lo in range(0, N, 1_000_000):  # the generator itself: every row has its total
+        rowsum = X[lo:lo + 1_000_000].view(torch.int16).to(torch.int32).bitwise_and(0xFFFF).sum(dim=1)
+        assert torch.equal(rowsum, totals[lo:lo + 1_000_000])
     st = dev.DeviceStats(K)
     st.add_dense(X, max_count=500, max_total=500)
     info = st.check()
@@ -206,8 +208,8 @@ def test_large_synthetic_properties():
     uv = st.finalize()
     U = uv.Ui.view(K, uv.ldU)
     colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
-    for lo in range(0, N, 250_000):
-        colsum += X[lo:lo + 250_000].view(torch.int16).to(torch.int64).bitwise_and(0xFFFF).sum(dim=0)
+    for lo in range(0, N, 500_000):
+        colsum += X[lo:lo + 500_000].view(torch.int16).to(torch.int64).bitwise_and(0xFFFF).sum(dim=0)
     assert torch.equal(U.sum(dim=1), colsum)
     assert int(uv.Vi.sum()) == int(totals.to(torch.int64).sum())
     assert int(uv.Vi[0]) == N
