@@ -54,6 +54,12 @@ def test_abi_version_and_sizes_without_gpu():
     assert L.dme_solver_workspace_bytes(0, 1, 1) == -1
     assert L.dme_stats_workspace_bytes(10_000_000, 1000) > 256 * 1000 * 8
     assert L.dme_synth_scratch_bytes(500) > 0
+    # CSR: no partition workspace for small inputs or beyond the 32-bit entry offsets; otherwise at
+    # least one 8-byte record per stored entry
+    assert L.dme_stats_csr_workspace_bytes(1000, 1000, 50_000) == 0
+    assert L.dme_stats_csr_workspace_bytes(10**6, 1 << 32, 50_000) == 0
+    need = L.dme_stats_csr_workspace_bytes(10**6, 5 * 10**7, 50_000)
+    assert need >= 8 * 5 * 10**7 and need % 256 == 0
 
 
 def test_argument_validation_needs_no_gpu():
@@ -63,6 +69,10 @@ def test_argument_validation_needs_no_gpu():
     rc = L.dme_stats_dense_u16(0, 10, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG
     assert b"bad shape" in L.dme_last_error()
+    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 0, 0, 2, 0, 2, 0, 0, 0, 0, 0)
+    assert rc == _lib.ERR_INVALID_ARG and b"bad shape" in L.dme_last_error()
+    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 7, 0, 2, 0, 2, 0, 0, 0, 0, 0)
+    assert rc == _lib.ERR_INVALID_ARG and b"null output" in L.dme_last_error()
     rc = L.dme_suffix_scan(0, 0, 1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG
     with pytest.raises(ValueError):
