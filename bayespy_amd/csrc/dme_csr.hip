@@ -12,7 +12,8 @@
 //                       column bucket (bucket = CB consecutive columns) in LDS        [reads colidx]
 //   csr_offsets_kernel  + csr_bucket_scan_kernel: bucket-major exclusive offsets of every
 //                       (bucket, slab) run
-//   csr_scatter_kernel  batches of whole rows, entry-parallel: row totals by LDS atomics -> histV;
+//   csr_scatter_kernel  batches of whole rows, entry-parallel: row totals and row ids from LDS
+//                       prefix sums -> histV (LDS bins);
 //                       every entry becomes 8 bytes {column-in-bucket | count << cb, row total},
 //                       ordered by bucket in LDS, written in contiguous pieces to its bucket's
 //                       run                                                 [reads all, writes 8 B]
@@ -25,7 +26,7 @@
 //
 // Integer results are exact and order-independent; init_acc is summed in arrival order (fp64), so
 // its last bits vary from run to run, as with the atomics path.  Without a workspace, or for inputs
-// too small to repay five launches, the atomics kernel runs.
+// too small to repay six launches, the atomics kernel runs.
 #include "dme_common.h"
 
 namespace {

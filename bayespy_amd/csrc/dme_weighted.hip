@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void stats_weighted_kernel(
         if (lane == 0 && total > 0) {
             if ((long long)total < tbins) {
                 atomicAdd(&histVW[total], w);
-                atomicMax((u64*)maxtot, total);
+                // the maxima settle after a few rows: look before paying for an atomic
+                if ((u64)__builtin_nontemporal_load(maxtot) < total) atomicMax((u64*)maxtot, total);
             } else {
                 bad_rows++;
             }
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void stats_weighted_kernel(
             if (v < 0) { neg++; continue; }
             if ((long long)v < nbins) {
                 atomicAdd(&histW[k * nbins + v], w);
-                atomicMax((u64*)&maxcol[k], (u64)v);
+                if (__builtin_nontemporal_load(&maxcol[k]) < (long long)v) atomicMax((u64*)&maxcol[k], (u64)v);
             } else {
                 bad_cells++;
             }
