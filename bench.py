@@ -217,6 +217,17 @@ def main():
                        % (ns, t_stats_cpu, N, t_solve_cpu, sol["n_iters"], sol["n_evals"])),
             "host_cpus": os.cpu_count(),
         }
+        # the reference's own cost model — interpreted loops per row — on a smaller sample
+        from oracle import py_port
+        npy = min(2000, ns)
+        rows_py = Xh[:npy].astype(np.int64).tolist()
+        t0 = time.perf_counter()
+        py_port.build(rows_py, K)
+        t_py = time.perf_counter() - t0
+        line["cpu_baseline"]["cpython_port"] = {
+            "value": npy / t_py, "unit": "rows/s", "cores": 1,
+            "sample": "oracle/py_port.py (CPython loops of DE/dme.py:113-123 + DE/fdp.py:87-89) on "
+                      "%d rows: %.2f s; statistics build only" % (npy, t_py)}
         rel = float(np.max(np.abs(out["alpha"] - sol["alpha"]) / np.abs(sol["alpha"])))
         line["cpu_baseline"]["gpu_vs_oracle_max_rel_alpha_err"] = rel
 

@@ -172,3 +172,16 @@ def test_cpt_oracle_matches_reference(idx):
     np.testing.assert_allclose(out["alpha"], s["final"], rtol=1e-9)
     np.testing.assert_allclose([t["loss"] for t in out["trace"]], [t["loss"] for t in s["trace"]],
                                rtol=1e-12)
+
+
+def test_cpython_port_matches_the_c_oracle(oracle):
+    """oracle/py_port.py (the timing stand-in for the reference's interpreted loops) builds the same
+    U/V and mean accumulator as the C oracle, bit for bit."""
+    from oracle import py_port
+    fx = load_golden("dirmult_k50")
+    X = fx["X"].astype(np.int32)[:400]
+    data, acc = py_port.build(X.tolist(), fx["K"])
+    ref = oracle.append_rows(X)
+    assert data.U == [list(map(int, u)) for u in ref.U]
+    assert data.V == list(map(int, ref.V))
+    assert acc == ref.init_acc.tolist()
