@@ -201,6 +201,20 @@ __device__ __forceinline__ void block_reduce_fused(DmeAcc (&a)[NA], double (&d)[
     __syncthreads();
 }
 
+// Block minimum, returned to every thread (used off the hot path only).
+__device__ double block_min_f64(double x, BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) x = fmin(x, __shfl_xor(x, d));
+    if (lane == 0) sh.fdbl[0][wave] = x;
+    __syncthreads();
+    double r = sh.fdbl[0][0];
+#pragma unroll
+    for (int w = 1; w < STEP_WAVES; ++w) r = fmin(r, sh.fdbl[0][w]);
+    __syncthreads();
+    return r;
+}
+
 __device__ __forceinline__ DmeAcc block_sum_acc(DmeAcc v, BlockShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = dme_wave_sum_acc(v);
@@ -499,8 +513,9 @@ __device__ bool logspace_trial(const double* alpha, const double* g, const doubl
     return true;
 }
 
-// sum(trial) and the positivity test of testTrialPriors (DE/dme.py:98-100)
-__device__ void finish_trial(Ctrl* ctrl, const double* trial, long long K, BlockShared& sh) {
+// sum(trial) and the positivity test of testTrialPriors (DE/dme.py:98-100); returns whether the
+// trial is valid (every alpha > 0) to every thread
+__device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, BlockShared& sh) {
     const int tid = threadIdx.x;
     DmeAcc none[1] = {{0, 0}};
     double a[1] = {0.0};
@@ -515,6 +530,7 @@ __device__ void finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
         ctrl->A_trial = a[0];
         ctrl->trial_valid = bad ? 0 : 1;
     }
+    return !bad;
 }
 
 __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* alpha, long long K,
@@ -610,11 +626,29 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
         }
     } else {  // PH_LOGSPACE / PH_HALVING: the while loop of :176-180
         if (lossT > currentLoss) {
-            learnRate = __dmul_rn(learnRate, 0.9);
-            for (long long k = tid; k < K; k += STEP_BLOCK)
-                w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __dmul_rn(w.g_cur[k], learnRate));
-            __syncthreads();
-            finish_trial(c, w.alpha_trial, K, sh);
+            // A trial with an alpha <= 0 scores inf without an evaluation (:98-100) and the loop
+            // goes on: those rounds are walked here instead of costing a launch pair each (a bad
+            // start on a large vocabulary takes ~200 of them).  The walk ends: the step shrinks
+            // towards the current point, whose alphas are positive.
+            // Rounds whose step is still far too long need no pass over the columns: with
+            // r = min_k alpha_k / -g_k over the falling columns, learnRate > r (1 + 1e-9) leaves
+            // that column at or below zero whatever the rounding.  The rate itself is still
+            // multiplied round by round, so the sequence of rates is the reference's.
+            double r = INFINITY;
+            for (long long k = tid; k < K; k += STEP_BLOCK) {
+                const double gk = w.g_cur[k];
+                if (gk < 0.0) r = fmin(r, __ddiv_rn(w.alpha_cur[k], -gk));
+            }
+            r = __dmul_rn(block_min_f64(r, sh), 1.000000001);
+            while (__dmul_rn(learnRate, 0.9) > r) learnRate = __dmul_rn(learnRate, 0.9);
+            bool ok;
+            do {
+                learnRate = __dmul_rn(learnRate, 0.9);
+                for (long long k = tid; k < K; k += STEP_BLOCK)
+                    w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __dmul_rn(w.g_cur[k], learnRate));
+                __syncthreads();
+                ok = finish_trial(c, w.alpha_trial, K, sh);
+            } while (!ok);
             store_state(PH_HALVING);
             return;
         }
