@@ -302,6 +302,7 @@ struct CsrArgs {
     const int* colidx;
     const int* vals;
     long long N, K, nbins, tbins, rows_per_slab, vlim;
+    u64 capacity;  // records the workspace holds (the caller's nnz)
     int sh, NB, TBL;
     const u64* rel;
     const u64* start;
@@ -403,6 +404,10 @@ __global__ __launch_bounds__(CSR_SBLOCK, 4) void csr_scatter_kernel(CsrArgs a) {
     long long r1 = r0 + a.rows_per_slab;
     if (r1 > a.N) r1 = a.N;
     if (r0 >= r1) return;  // uniform: nothing was written yet
+    if (a.start[a.NB] > a.capacity) {  // rowptr spans more entries than the caller's nnz: no writes
+        if (g == 0 && tid == 0) atomicAdd(&a.status[6], 1ULL);
+        return;
+    }
     const u32 cmask = (1u << a.sh) - 1;
     u32 maxv = 0;
     u64 maxt = 0, bad = 0, big = 0;
@@ -673,6 +678,7 @@ struct BucketArgs {
     const uint2* entries;
     const u64* start;  // [NB + 1]
     long long K, nbins;
+    u64 capacity;
     int sh, NB, BL, W, AC;
     u64* hist;
     double* init_acc;
@@ -697,6 +703,7 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_bucket_kernel(BucketArgs a) {
     const u32 acmask = (u32)a.AC - 1;
     const int tid = threadIdx.x;
     const u64 total = a.start[a.NB];
+    if (total > a.capacity) return;  // flagged by the scatter kernel
     const u64 piece = csr_piece(total, a.W);
     u64 pos = piece * blockIdx.x;
     u64 end = pos + piece;
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_bucket_kernel(BucketArgs a) {
 __global__ __launch_bounds__(CSR_BLOCK) void csr_reduce_kernel(BucketArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const u64 s0 = a.start[b], s1 = a.start[b + 1];
-    if (s1 == s0) return;
+    if (s1 == s0 || a.start[a.NB] > a.capacity) return;
     const int CB = 1 << a.sh;
     const u64 piece = csr_piece(a.start[a.NB], a.W);
     const int w_lo = (int)(s0 / piece), w_hi = (int)((s1 - 1) / piece);
@@ -871,6 +878,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     a.N = N; a.K = K; a.nbins = nbins; a.tbins = tbins;
     a.rows_per_slab = p.rows_per_slab;
     a.vlim = p.vlim;
+    a.capacity = (u64)nnz;
     a.sh = p.sh; a.NB = p.NB;
     a.TBL = (int)(tbins < CSR_TBL_MAX ? tbins : CSR_TBL_MAX);
     a.rel = rel; a.start = start; a.entries = entries;
@@ -881,7 +889,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     hipLaunchKernelGGL(csr_scatter_kernel, dim3(p.G), dim3(CSR_SBLOCK), lds_scatter, s, a);
 
     BucketArgs bk{};
-    bk.entries = entries; bk.start = start; bk.K = K; bk.nbins = nbins;
+    bk.entries = entries; bk.start = start; bk.K = K; bk.nbins = nbins; bk.capacity = (u64)nnz;
     bk.sh = p.sh; bk.NB = p.NB; bk.BL = p.BL; bk.W = p.W; bk.AC = p.AC;
     bk.hist = (u64*)hist; bk.init_acc = init_acc;
     const size_t lds_bucket = 8 * (size_t)p.AC * p.CB + 4 * (size_t)p.CB * p.BL;

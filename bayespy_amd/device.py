@@ -403,6 +403,8 @@ class DeviceStats:
             st = self._pinned.numpy().copy()
         else:
             st = self.status.cpu().numpy()
+        if st[6]:
+            raise ValueError("CSR input inconsistent: rowptr spans more entries than colidx / vals hold")
         if st[3]:
             raise ValueError(f"{int(st[3])} negative counts (or column indices out of range)")
         if st[1] or st[2]:

@@ -42,7 +42,7 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
 
-    One integer SUM carries everything: hist || histV || the four additive status words || one
+    One integer SUM carries everything: hist || histV || the additive status words || one
     slot per rank for its two observed maxima || one slot per rank for the bit patterns of its K
     mean accumulators.  A rank fills only its own slots, so the sum hands every rank all the
     per-rank values unchanged; the maxima are then taken locally and the fp64 accumulators are
@@ -63,7 +63,7 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     slots = torch.zeros(world, 2 + K, dtype=torch.int64, device=hist.device)
     slots[rank, :2] = status[4:6]
     slots[rank, 2:] = init_acc.view(torch.int64)
-    flat = torch.cat([hist, histV, status[:4], slots.view(-1)])
+    flat = torch.cat([hist, histV, status[:4], status[6:8], slots.view(-1)])  # [4:6] are maxima
     if flat.is_cuda and dist.get_backend(group) == "gloo":
         # rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor
         # was seen to hang when issued behind a long-running kernel of the same process; RCCL
@@ -71,9 +71,10 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
         torch.cuda.current_stream(flat.device).synchronize()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     nh, nv = hist.numel(), histV.numel()
-    slots = flat[nh + nv + 4:].view(world, 2 + K)
+    slots = flat[nh + nv + 6:].view(world, 2 + K)
     out_status = torch.zeros_like(status)
     out_status[:4] = flat[nh + nv:nh + nv + 4]
+    out_status[6:8] = flat[nh + nv + 4:nh + nv + 6]
     out_status[4:6] = slots[:, :2].max(dim=0).values
     parts = slots[:, 2:].contiguous().view(torch.float64)
     acc = parts[0].clone()

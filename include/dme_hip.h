@@ -58,7 +58,8 @@ int dme_device_cus(void);
  *     [0] rows processed        [1] cells with count >= nbins (NOT counted: result incomplete)
  *     [2] rows with total >= tbins (NOT counted)              [3] negative cells (i32 only)
  *     [4] max count seen        [5] max row total seen
- * The caller must check status[1..3] == 0 (they are data errors, reported after the fact so
+ *     [6] CSR only: rowptr spans more entries than the nnz passed (nothing was counted)
+ * The caller must check status[1..3] == 0 and status[6] == 0 (they are data errors, reported after the fact so
  * that the pass stays asynchronous).
  *
  * X is row-major, `ld` elements between rows (ld >= K).  Dense kernels need

@@ -321,3 +321,41 @@ def test_csr_partitioned_row_totals_beyond_lds_bins(oracle):
     ref = oracle.append_rows_csr(rowptr, col, val, K)
     _assert_uv_equal(st.finalize(), ref)
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+
+
+def test_csr_rowptr_beyond_nnz_is_refused():
+    """rowptr that spans more entries than the stated nnz (the partition workspace is sized by nnz):
+    the pass writes nothing and flags it; check() raises."""
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    N, K, per = 4000, 3000, 20
+    nnz = N * per
+    rowptr = torch.arange(0, nnz + 1, per, dtype=torch.int64, device="cuda")
+    col = torch.from_numpy(rng.integers(0, K, size=nnz).astype(np.int32)).cuda()
+    val = torch.ones(nnz, dtype=torch.int32, device="cuda")
+    hist, histV, acc, status = _csr_direct_nnz(rowptr, col, val, K, 4, 64, claimed_nnz=nnz // 2)
+    assert int(status[6]) == 1 and int(hist.sum()) == 0
+    st = dev.DeviceStats(K, 3, 63)
+    st.status += status
+    with pytest.raises(ValueError, match="rowptr spans more entries"):
+        st.check()
+
+
+def _csr_direct_nnz(rowptr, colidx, vals, K, nbins, tbins, claimed_nnz):
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    N = rowptr.numel() - 1
+    hist = torch.zeros(K * nbins, dtype=torch.int64, device="cuda")
+    histV = torch.zeros(tbins, dtype=torch.int64, device="cuda")
+    acc = torch.zeros(K, dtype=torch.float64, device="cuda")
+    status = torch.zeros(8, dtype=torch.int64, device="cuda")
+    need = L.dme_stats_csr_workspace_bytes(N, claimed_nnz, K)
+    assert need > 0
+    keep = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    off = (-keep.data_ptr()) % 256
+    _lib.check(L.dme_stats_csr_i32(rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), N, claimed_nnz, K,
+                                   hist.data_ptr(), nbins, histV.data_ptr(), tbins, acc.data_ptr(),
+                                   status.data_ptr(), keep.data_ptr() + off, need,
+                                   torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    return hist, histV, acc, status
