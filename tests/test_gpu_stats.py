@@ -359,3 +359,17 @@ def _csr_direct_nnz(rowptr, colidx, vals, K, nbins, tbins, claimed_nnz):
                                    torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     return hist, histV, acc, status
+
+
+def test_csr_without_entries():
+    """CSR rows that store nothing: rows are counted, no statistics change."""
+    dev = _dev()
+    st = dev.DeviceStats(7)
+    rowptr = torch.zeros(6, dtype=torch.int64, device="cuda")
+    empty = torch.zeros(0, dtype=torch.int32, device="cuda")
+    st.add_csr(rowptr, empty, empty)
+    info = st.check()
+    assert info["rows"] == 5 and info["max_count"] == 0 and info["max_total"] == 0
+    assert int(st.hist.sum()) == 0 and int(st.histV.sum()) == 0
+    U, V = st.finalize().to_lists()
+    assert U == [[] for _ in range(7)] and V == []
