@@ -70,7 +70,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <int BYTES, int ND>
 __device__ __forceinline__ void load_chunk(const void* p, u32 (&d)[ND]) {
-    if constexpr (BYTES == 16) {
+    if constexpr (BYTES == 32) {
+        u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+        u32x4 u = __builtin_nontemporal_load((const u32x4*)p + 1);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w;
+    } else if constexpr (BYTES == 16) {
         u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     } else if constexpr (BYTES == 8) {
@@ -119,21 +124,28 @@ struct StatsCfg {
     // 16-column uint16 kernel fits; wider lanes (and int32's 16 columns) take 512 or 256.
     static constexpr int BLOCK = (J * E >= 64) ? 256 : ((J * E > 16) ? 512 : 1024);
     // row groups per register buffer (two buffers): enough 16-byte loads in flight per CU
-    static constexpr int RB = (J <= 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1);
+    // (ES == 4 with E == 8 is the packed-int32 kernel: its raw buffers are twice the size)
+    static constexpr int RB = (ES == 4 && E == 8) ? 1 : ((J <= 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1));
 };
 
-// T: element type (unsigned short | int).  E: elements per vector load.  J: vectors per lane and
-// row.  MULTI: a wave carries R = 64/C rows at once (then J == 1).
-template <typename T, int E, int J, bool MULTI>
+// T: element type (unsigned short | int).  E: elements per vector (chunk).  J: vectors per lane
+// and row.  MULTI: a wave carries R = 64/C rows at once (then J == 1).
+// PACK (T = int, E = 8): int32 rows whose counts are, with rare exceptions, below 65536: a chunk
+// is loaded as two 16-byte vectors, the exceptions (and negatives) are settled one by one, and the
+// eight counts are packed into four dwords that then take the uint16 code - the int32 kernel pays
+// per element what the uint16 kernel pays (~half the instructions of the plain int32 path).
+template <typename T, int E, int J, bool MULTI, bool PACK>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
-    constexpr bool IS16 = sizeof(T) == 2;
+    constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
+    constexpr bool IS16 = RAW16 || PACK;    // the cells are processed as packed 16-bit counts
     constexpr int BYTES = E * (int)sizeof(T);
     constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
+    constexpr int NDP = IS16 ? (E >= 2 ? E / 2 : 1) : ND;  // dwords per vector once packed
     constexpr int PW = E >= 2 ? E / 2 : 1;          // LDS words per vector (2 columns per word)
     constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T)>::BLOCK;
     constexpr int W = BLOCK / 64;
     constexpr int RB = StatsCfg<J, E, (int)sizeof(T)>::RB;
-    typedef typename std::conditional<IS16, u32, u64>::type SumT;
+    typedef typename std::conditional<RAW16, u32, u64>::type SumT;
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -210,7 +222,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
         SumT tot[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if constexpr (IS16) {
+            if constexpr (RAW16) {
                 u32 s = 0;
 #pragma unroll
                 for (int j = 0; j < J; ++j)
@@ -317,40 +329,74 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             for (int j = 0; j < J; ++j) {
                 const int chunk = c + 64 * j;
                 if constexpr (IS16) {
+                    u32 dwl[NDP];
+                    if constexpr (PACK) {
+                        // counts >= 65536 and negatives (huge as unsigned) are settled here and
+                        // cleared; what is left fits 16 bits
+                        u32 mr = b.d[rb][j][0];
+#pragma unroll
+                        for (int e = 1; e < E; ++e) mr = max(mr, b.d[rb][j][e]);
+                        if (__builtin_expect(mr > 0xFFFFu, 0)) {
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const int v = (int)b.d[rb][j][e];
+                                if (v < 0) {
+                                    atomicAdd(&sh_stat[3], 1ULL);
+                                    b.d[rb][j][e] = 0;
+                                } else if (v > 0xFFFF) {
+                                    atomicMax(&sh_stat[4], (u64)v);
+                                    if ((long long)v < nbins) {
+                                        const long long k = (long long)opaque(chunk) * E + e;
+                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                    } else {
+                                        atomicAdd(&sh_stat[1], 1ULL);
+                                    }
+                                    acc[j][e] = mean_add(acc[j][e], (double)v, w);
+                                    b.d[rb][j][e] = 0;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < NDP; ++q)
+                            dwl[q] = b.d[rb][j][2 * q] | (b.d[rb][j][2 * q + 1] << 16);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NDP; ++q) dwl[q] = b.d[rb][j][q];
+                    }
                     // rare path first: any count > B in this vector?  packed 16-bit max over the
                     // vector, then min(m, B|B) != m  <=>  some half exceeds B
-                    u32 m = b.d[rb][j][0];
+                    u32 m = dwl[0];
 #pragma unroll
-                    for (int q = 1; q < ND; ++q) m = pk_max_u16(m, b.d[rb][j][q]);
+                    for (int q = 1; q < NDP; ++q) m = pk_max_u16(m, dwl[q]);
                     if (__builtin_expect(pk_min_u16(m, Bpk) != m, 0) && !DBG(4)) {
 #pragma unroll
-                        for (int q = 0; q < ND; ++q)
+                        for (int q = 0; q < NDP; ++q)
 #pragma unroll
                             for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
-                                const u32 v = h ? (b.d[rb][j][q] >> 16) : (b.d[rb][j][q] & 0xffffu);
+                                const u32 v = h ? (dwl[q] >> 16) : (dwl[q] & 0xffffu);
                                 if (v > (u32)B) {
                                     const long long k = (long long)opaque(chunk) * E + 2 * q + h;
                                     atomicMax(&sh_stat[4], (u64)v);
                                     if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
                                     else atomicAdd(&sh_stat[1], 1ULL);
                                     acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, w);
-                                    b.d[rb][j][q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
+                                    dwl[q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
                                 }
                             }
                     }
                     // one exec-masked region per DME_GROUP dwords: a lane enters it when any of its
                     // 2*DME_GROUP counts is non-zero; zero halves inside go to the sink row
-                    constexpr int QG = (ND % DME_GROUP == 0) ? DME_GROUP : 1;
+                    constexpr int QG = (NDP % DME_GROUP == 0) ? DME_GROUP : 1;
 #pragma unroll
-                    for (int q0 = 0; q0 < ND; q0 += QG) {
-                        u32 any = b.d[rb][j][q0];
+                    for (int q0 = 0; q0 < NDP; q0 += QG) {
+                        u32 any = dwl[q0];
 #pragma unroll
-                        for (int t = 1; t < QG; ++t) any |= b.d[rb][j][q0 + t];
+                        for (int t = 1; t < QG; ++t) any |= dwl[q0 + t];
                         if (__builtin_expect(any != 0, 1)) {  // some lane of the wave almost always is
 #pragma unroll
                             for (int t = 0; t < QG; ++t) {
                                 const int q = q0 + t;
-                                const u32 dw = b.d[rb][j][q];
+                                const u32 dw = dwl[q];
                                 const u32 lo = dw & 0xffffu;
                                 const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
                                 if (!DBG(1))
@@ -572,6 +618,7 @@ struct Plan {
     int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg;
     long long grid, part_words;
     bool multi;
+    bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
 };
 
 int plan_dense(int elem_bytes, const void* X, long long N, long long K, long long ld,
@@ -580,8 +627,12 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const uintptr_t addr = (uintptr_t)X;
     while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
     if (addr % elem_bytes) return dme_set_error(DME_ERR_INVALID_ARG, "X is not element-aligned");
+    // int32 rows of 16-byte-aligned chunks of 8 columns, at least one chunk per lane
+    const bool pack = elem_bytes == 4 && E == 4 && K % 8 == 0 && K / 8 >= 64;
+    if (pack) E = 8;
     const long long C = K / E;
     Plan p{};
+    p.pack = pack;
     p.E = E;
     p.C = (int)C;
     p.multi = C < 64;
@@ -641,9 +692,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     return DME_OK;
 }
 
-template <typename T, int E, int J, bool MULTI>
+template <typename T, int E, int J, bool MULTI, bool PACK = false>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI>;
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB)
     DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kLdsBudgetBytes + 1024));
@@ -700,7 +751,18 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
                 p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, 0};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
-    switch (p.E) {
+    if constexpr (sizeof(T) == 4) {
+        if (p.pack) {
+            switch (p.J) {
+                case 1: rc = launch_dense<T, 8, 1, false, true>(a, p, s); break;
+                case 2: rc = launch_dense<T, 8, 2, false, true>(a, p, s); break;
+                case 4: rc = launch_dense<T, 8, 4, false, true>(a, p, s); break;
+                case 8: rc = launch_dense<T, 8, 8, false, true>(a, p, s); break;
+                default: rc = dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
+            }
+        }
+    }
+    if (!p.pack) switch (p.E) {
         case 1: rc = dispatch_j<T, 1>(a, p, s); break;
         case 2: rc = dispatch_j<T, 2>(a, p, s); break;
         case 4: rc = dispatch_j<T, 4>(a, p, s); break;

@@ -312,9 +312,9 @@ class DeviceStats:
         """Layouts the vector loads cannot take (odd row pitch / K with many columns): copy into
         a 16-byte-aligned matrix whose K is padded with zero columns, run that, keep columns < K.
         Costs one extra pass; only awkward layouts come here."""
-        per16 = 16 // X.element_size()
-        Kp = -(-self.K // per16) * per16
-        if Kp // per16 > 64 * 8:
+        # both element types run in chunks of 8 columns (int32: the packed kernel), 8 chunks per lane
+        Kp = -(-self.K // 8) * 8
+        if Kp // 8 > 64 * 8:
             return self._add_dense_as_csr(X, max_count, max_total)
         Xp = torch.zeros((X.shape[0], Kp), dtype=X.dtype, device=self.device)
         Xp[:, :self.K] = X
@@ -333,7 +333,7 @@ class DeviceStats:
         return self.merge_(cut)
 
     def _add_dense_as_csr(self, X, max_count, max_total):
-        """Dense rows wider than the dense kernels take (K > 4096 uint16 / 2048 int32): compress to
+        """Dense rows wider than the dense kernels take (K > 4096): compress to
         CSR on the device (torch, row blocks) and use the CSR entry."""
         step = max(1, (32 << 20) // max(self.K, 1))
         for lo in range(0, X.shape[0], step):

@@ -64,8 +64,10 @@ int dme_device_cus(void);
  *
  * X is row-major, `ld` elements between rows (ld >= K).  Dense kernels need
  * ceil(K / E / 64) <= 8 where E is the largest power of two <= 16/sizeof(elem) that divides K, ld
- * and the element offset of X (K <= 4096 for 16-byte-aligned uint16 rows); otherwise
- * DME_ERR_UNSUPPORTED (use the CSR entry).
+ * and the element offset of X (K <= 4096 for 16-byte-aligned uint16 rows); int32 rows with
+ * K % 8 == 0, K >= 512 and 16-byte-aligned rows run in chunks of 8 columns like uint16 rows (K <= 4096;
+ * counts of 65536 and more are legal and settled one by one).  Otherwise DME_ERR_UNSUPPORTED (use
+ * the CSR entry).
  * workspace: dme_stats_workspace_bytes(N, K) bytes [dev], 256-byte aligned.
  * ------------------------------------------------------------------------------------------- */
 int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);

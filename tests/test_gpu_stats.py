@@ -72,8 +72,6 @@ SHAPES = [
 def test_random_shapes_vs_oracle(oracle, N, K, vmax, density, dtype):
     if dtype == "u16" and vmax > 65535:
         vmax = 65535
-    if dtype == "i32" and K > 2048:
-        pytest.skip("beyond the dense int32 kernel's K range")
     rng = np.random.default_rng(N * 1000 + K)
     X = rng.integers(1, vmax + 1, size=(N, K)) * (rng.random((N, K)) < density)
     # a few large values to exercise the global-atomic path beside the LDS bins
@@ -373,3 +371,26 @@ def test_csr_without_entries():
     assert int(st.hist.sum()) == 0 and int(st.histV.sum()) == 0
     U, V = st.finalize().to_lists()
     assert U == [[] for _ in range(7)] and V == []
+
+
+def test_packed_int32_kernel_exceptions(oracle):
+    """int32 rows of 8-column chunks take the packed kernel (counts travel as 16-bit pairs): counts
+    of 65536 and more are settled one by one and must land in the same bins; negatives are reported."""
+    dev = _dev()
+    rng = np.random.default_rng(42)
+    for K in (512, 1000, 2048, 4096):
+        N = 300
+        X = rng.integers(1, 40, size=(N, K)) * (rng.random((N, K)) < 0.05)
+        for v in (65535, 65536, 70000, 200000, 65537):
+            X[rng.integers(0, N), rng.integers(0, K)] = v
+        ref = oracle.append_rows(X.astype(np.int32))
+        st, uv, info = _build(X, "i32")
+        assert info["max_count"] == 200000
+        _assert_uv_equal(uv, ref)
+        np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
+        Xn = X.copy()
+        Xn[5, 17] = -3
+        bad = dev.DeviceStats(K)
+        bad.add_dense(_to_dev(Xn, "i32"), max_count=200000, max_total=int(X.sum(axis=1).max()))
+        with pytest.raises(ValueError, match="negative"):
+            bad.check()
