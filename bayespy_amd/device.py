@@ -11,6 +11,7 @@ Reference mapping (DirichletEstimation/dirichletMultinomialEstimation.py = "DE/d
     DeviceUV.evaluate                 <- dirichLogProb / priorGradient / priorHessian* (:16-61)
     DeviceUV.solve                    <- findDirichletPriors (:126-190)
 """
+import contextlib
 import ctypes
 import logging
 
@@ -39,6 +40,14 @@ def require_gpu(device=None):
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
     return device
+
+
+_SAME_DEVICE = contextlib.nullcontext()
+
+
+def _on(device):
+    """Context that makes `device` current; a no-op (no driver calls) when it already is."""
+    return _SAME_DEVICE if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 def _stream():
@@ -118,7 +127,7 @@ class DeviceUV:
     def evaluate(self, alpha, hyperprior=0.0, Beta=None, W=None):
         """Returns (logprob, hconst, grad[K], hdiag[K], gradSq) as host values.  With Beta / W the
         (Beta, W) conjugate hyperprior of CPT/dme.py:20-87 replaces the scalar one."""
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             a = torch.as_tensor(np.asarray(alpha, dtype=np.float64)).to(self.device)
             if a.numel() != self.K:
                 raise ValueError(f"expected {self.K} alphas, got {a.numel()}")
@@ -148,7 +157,7 @@ class DeviceUV:
         exit (1/2/3), n_iters, n_evals, final_loss, trace (n_iters x 4: loss, gradSq, branch,
         learnRate), trace_alpha (n_iters x K or None).  With Beta / W: CPT/dme.py:156-219."""
         iterations = int(iterations)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             if isinstance(init_alphas, torch.Tensor):
                 a = init_alphas.detach().to(device=self.device, dtype=torch.float64).clone()
             else:
@@ -227,7 +236,7 @@ class DeviceStats:
         self.K = int(K)
         self.nbins = max(int(max_count), 1) + 1
         self.tbins = max(int(max_total), 1) + 1
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             # one zero-filled buffer (one memset): hist | histV | status | init_acc (fp64 zeros are
             # all-zero bits)
             nh, nv = self.K * self.nbins, self.tbins
@@ -298,7 +307,7 @@ class DeviceStats:
             max_count = mc if max_count is None else max_count
             max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             ws, wsb = self._workspace(X.shape[0])
             rc = fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
                     self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
@@ -319,7 +328,7 @@ class DeviceStats:
         Xp = torch.zeros((X.shape[0], Kp), dtype=X.dtype, device=self.device)
         Xp[:, :self.K] = X
         tmp = DeviceStats(Kp, max_count, max_total, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             ws, wsb = tmp._workspace(X.shape[0])
             fn = (_lib.lib().dme_stats_dense_i32 if X.dtype == torch.int32
                   else _lib.lib().dme_stats_dense_u16)
@@ -368,7 +377,7 @@ class DeviceStats:
             max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
         self.reserve(max_count, max_total)
         nnz = colidx.numel()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             need = _lib.lib().dme_stats_csr_workspace_bytes(N, nnz, self.K)
             ws, wsb = 0, 0
             if need > 0:
@@ -487,7 +496,7 @@ class DeviceStats:
         K, dev = self.K, self.device
         ldU = max(self.nbins - 1, 1)
         capV = max(self.tbins - 1, 1)
-        with torch.cuda.device(dev):
+        with _on(dev):
             # the scan writes every entry (padding included): no zero fill needed
             ibuf = torch.empty(K * ldU + capV + K + 1, dtype=torch.int64, device=dev)
             U, V = ibuf[:K * ldU], ibuf[K * ldU:K * ldU + capV]
@@ -501,7 +510,7 @@ class DeviceStats:
 
     def cli_init_alphas(self):
         """DE/fdp.py:104-108 on the device: init_acc / (sum + 0.01) + 0.01."""
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             a0 = torch.empty(self.K, dtype=torch.float64, device=self.device)
             _lib.check(_lib.lib().dme_cli_init_alphas(_ptr(self.init_acc), self.K, _ptr(a0),
                                                       _stream()))
@@ -544,7 +553,7 @@ class WeightedStats:
         if weights.dtype != torch.float64 or weights.numel() != X.shape[0]:
             raise ValueError("weights must be float64, one per row")
         self.reserve(max_count, max_total)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().dme_stats_dense_weighted_i32(
                 X.data_ptr(), _ptr(weights), X.shape[0], self.K, X.stride(0), _ptr(self.histW),
                 self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol), _ptr(self.maxtot),
@@ -561,7 +570,7 @@ class WeightedStats:
         """Adds the weighted suffix sums into a DeviceUV (whose U/V stop being integers)."""
         if uv.ldU < self.nbins - 1 or uv.capV < self.tbins - 1:
             raise ValueError("DeviceUV too small for the weighted statistics")
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _lib.check(_lib.lib().dme_suffix_scan_weighted(
                 _ptr(self.histW), self.K, self.nbins, _ptr(self.histVW), self.tbins,
                 _ptr(self.maxcol), _ptr(self.maxtot), _ptr(uv.Uf), uv.ldU, _ptr(uv.lenU),
@@ -573,7 +582,7 @@ class WeightedStats:
 def predicted_step(hconst, hdiag, grad, alphas=None, device=None):
     """getPredictedStep (alphas None) / getPredictedStepAlt on the device (DE/dme.py:67-80)."""
     device = require_gpu(device)
-    with torch.cuda.device(device):
+    with _on(device):
         hd = torch.as_tensor(np.asarray(hdiag, dtype=np.float64)).to(device)
         g = torch.as_tensor(np.asarray(grad, dtype=np.float64)).to(device)
         K = g.numel()
@@ -597,7 +606,7 @@ def synth_dirmult(N, K, alpha, totals, seed, dtype=torch.uint16, row_offset=0, d
     """Synthetic DirichletMultinomial(totals[i], alpha) rows generated on the device
     (dme_synth_dirmult).  totals: int32 device tensor [N].  Returns an N x K tensor."""
     device = require_gpu(device)
-    with torch.cuda.device(device):
+    with _on(device):
         alpha = np.asarray(alpha, dtype=np.float64)
         cdf = torch.from_numpy(np.cumsum(alpha)).to(device)
         totals = totals.to(device=device, dtype=torch.int32).contiguous()
