@@ -77,24 +77,23 @@ def load_data(stdin, K, sampleRate, M, delimiter):
             text = raw.decode() if isinstance(raw, bytes) else raw
 
     if idx == 0:
+        # the reference's row loop: csv.reader + int() per cell, one Bernoulli draw per row for
+        # -s, random thinning of rows above the -M cap (DE/fdp.py:75-92)
         import io
-        reader = csv.reader(io.StringIO(text) if text is not None else stdin,
-                            delimiter=delimiter)
-        for row in reader:
+        source = io.StringIO(text) if text is not None else stdin
+        for fields in csv.reader(source, delimiter=delimiter):
             idx += 1
-
-            if (random.random() < sampleRate):
-                data = list(map(int, row))
-                if (len(data) != K):
-                    logging.error("There are %s categories, but line has %s counts." % (K, len(data)))
-                    logging.error("line %s: %s" % (idx, data))
-
-                while sum(data) > M: data[Sample.drawCategory(data)] -= 1
-
+            if random.random() < sampleRate:
+                counts = [int(f) for f in fields]
+                if len(counts) != K:
+                    logging.error("There are %s categories, but line has %s counts." % (K, len(counts)))
+                    logging.error("line %s: %s" % (idx, counts))
+                while sum(counts) > M:
+                    counts[Sample.drawCategory(counts)] -= 1
                 # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
-                dataObj.appendRow(data, 1)
-
-            if (idx % 1000000) == 0: logging.debug("Loading Data: %s rows done" % idx)
+                dataObj.appendRow(counts, 1)
+            if idx % 1000000 == 0:
+                logging.debug("Loading Data: %s rows done" % idx)
     return dataObj, idx
 
 
@@ -103,13 +102,13 @@ def main(argv=None, stdin=None, stdout=None):
     stdout = sys.stdout if stdout is None else stdout
     startTime = time.time()
     parser = OptionParser()
-    parser.add_option('-s', '--sampleRate', dest='sampleRate', default='1', help='If set to 1, sample every row; if set <1, each row is selected independently on this probability')
-    parser.add_option('-K', '--numCategories', dest='K', default='2', help='The number of (tab separated) categories that are being counted')
-    parser.add_option('-M', '--maxCountPerRow', dest='M', type=int, default=sys.maxsize, help='The maximum number of the count per row.  Setting this lower decreases the running time')
-    parser.add_option("-L", '--loglevel', action="store", dest="loglevel", default='DEBUG', help="don't print status messages to stdout. choose among (ERROR|WARNING|INFO|DEBUG)")
-    parser.add_option('-H', '--hyperPrior', dest='H', default='0', help='The hyperprior of the Dirichlet (number): a higher value indicates more bias towards tight dirichlets (very close to a single multinomial). Normally choose 0.')
-    parser.add_option('-i', '--iterations', dest='iterations', default='50', help='Stop at this number of iterations if the results have not converged.')
-    parser.add_option('-d', '--delimiter', dest='delimiter', default='\t', help='The delimited of your CSV file (default is tab)')
+    parser.add_option('-s', '--sampleRate', dest='sampleRate', default='1', help='keep each input row with this probability (1 keeps all)')
+    parser.add_option('-K', '--numCategories', dest='K', default='2', help='number of count columns per row')
+    parser.add_option('-M', '--maxCountPerRow', dest='M', type=int, default=sys.maxsize, help='rows whose counts sum to more are thinned down to this total')
+    parser.add_option("-L", '--loglevel', action="store", dest="loglevel", default='DEBUG', help="logging level of the status messages on stderr (ERROR|WARNING|INFO|DEBUG)")
+    parser.add_option('-H', '--hyperPrior', dest='H', default='0', help='scalar hyperprior lambda (0 = plain maximum likelihood)')
+    parser.add_option('-i', '--iterations', dest='iterations', default='50', help='upper bound on Newton iterations')
+    parser.add_option('-d', '--delimiter', dest='delimiter', default='\t', help='column delimiter of the input (default: tab)')
 
     (options, args) = parser.parse_args(argv)
 
