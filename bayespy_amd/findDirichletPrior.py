@@ -50,51 +50,88 @@ def _parse_fast(raw, delimiter, K):
     return out[:n]
 
 
+_CHUNK_BYTES = 256 << 20  # stdin is parsed and counted in pieces of this size
+
+
+def _row_loop(lines, dataObj, K, sampleRate, M, delimiter, idx):
+    """The reference's row loop: csv.reader + int() per cell, one Bernoulli draw per row for -s,
+    random thinning of rows above the -M cap (DE/fdp.py:75-92).  Returns the rows read so far."""
+    for fields in csv.reader(lines, delimiter=delimiter):
+        idx += 1
+        if random.random() < sampleRate:
+            counts = [int(f) for f in fields]
+            if len(counts) != K:
+                logging.error("There are %s categories, but line has %s counts." % (K, len(counts)))
+                logging.error("line %s: %s" % (idx, counts))
+            while sum(counts) > M:
+                counts[Sample.drawCategory(counts)] -= 1
+            # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
+            dataObj.appendRow(counts, 1)
+        if idx % 1000000 == 0:
+            logging.debug("Loading Data: %s rows done" % idx)
+    return idx
+
+
 def load_data(stdin, K, sampleRate, M, delimiter):
     """The load loop of DE/fdp.py:66-93 -> (CompressedRowData, rows read)."""
-    #####
-    # Load Data
-    #####
     csv.field_size_limit(1000000000)
     logging.debug("Loading data")
-
     dataObj = DME.CompressedRowData(K)
 
-    idx = 0
-    text = None
     # Fast path (libdme_hip's multi-threaded parser): every row is kept (-s 1) and uncapped (no -M),
-    # so no per-row random draw decides anything.  Text outside its strict grammar falls back to
-    # the reference's own loop below, which keeps the reference's error behaviour.
-    if sampleRate >= 1.0 and M == sys.maxsize and len(delimiter) == 1:
-        raw = stdin.buffer.read() if hasattr(stdin, "buffer") else stdin.read()
-        X = _parse_fast(raw, delimiter, K)
-        if X is not None:
-            idx = X.shape[0]
-            for done in range(1000000, idx + 1, 1000000):
+    # so no per-row random draw decides anything.  stdin is read in pieces that end on a line
+    # break; each piece is parsed, counted on the GPU and dropped, so memory stays bounded whatever
+    # the input size.  From the first piece outside the parser's strict grammar onwards the
+    # reference's own loop takes over (it keeps the reference's error behaviour).
+    fast = sampleRate >= 1.0 and M == sys.maxsize and len(delimiter) == 1
+    if not fast:
+        return dataObj, _row_loop(stdin, dataObj, K, sampleRate, M, delimiter, 0)
+
+    binary = hasattr(stdin, "buffer")
+    src = stdin.buffer if binary else stdin
+    idx = 0
+    carry = b"" if binary else ""
+    nl = b"\n" if binary else "\n"
+    while True:
+        block = src.read(_CHUNK_BYTES)
+        piece = carry + block
+        if block:
+            cut = piece.rfind(nl)
+            if cut < 0:  # no line break yet: keep reading
+                carry = piece
+                continue
+            piece, carry = piece[:cut + 1], piece[cut + 1:]
+        else:
+            carry = piece[:0]
+        if piece:
+            X = _parse_fast(piece, delimiter, K)
+            if X is None:
+                # hand this piece and everything after it to the reference's loop
+                import io
+                import itertools
+                text = piece.decode() if binary else piece
+                rest = carry.decode() if binary else carry
+                tail = io.TextIOWrapper(src) if binary else src
+                lines = itertools.chain(text.splitlines(True), _lines_after(rest, tail))
+                return dataObj, _row_loop(lines, dataObj, K, sampleRate, M, delimiter, idx)
+            before = idx
+            idx += X.shape[0]
+            for done in range((before // 1000000 + 1) * 1000000, idx + 1, 1000000):
                 logging.debug("Loading Data: %s rows done" % done)
             dataObj.appendMatrix(X)
-        else:
-            text = raw.decode() if isinstance(raw, bytes) else raw
-
-    if idx == 0:
-        # the reference's row loop: csv.reader + int() per cell, one Bernoulli draw per row for
-        # -s, random thinning of rows above the -M cap (DE/fdp.py:75-92)
-        import io
-        source = io.StringIO(text) if text is not None else stdin
-        for fields in csv.reader(source, delimiter=delimiter):
-            idx += 1
-            if random.random() < sampleRate:
-                counts = [int(f) for f in fields]
-                if len(counts) != K:
-                    logging.error("There are %s categories, but line has %s counts." % (K, len(counts)))
-                    logging.error("line %s: %s" % (idx, counts))
-                while sum(counts) > M:
-                    counts[Sample.drawCategory(counts)] -= 1
-                # the mean accumulator of DE/fdp.py:87-89 is computed by the statistics kernel
-                dataObj.appendRow(counts, 1)
-            if idx % 1000000 == 0:
-                logging.debug("Loading Data: %s rows done" % idx)
+        if not block:
+            break
     return dataObj, idx
+
+
+def _lines_after(prefix, stream):
+    """Lines of prefix + the rest of stream (prefix is the unfinished line read ahead)."""
+    first = True
+    for line in stream:
+        yield prefix + line if first else line
+        first = False
+    if first and prefix:
+        yield prefix
 
 
 def main(argv=None, stdin=None, stdout=None):

@@ -1,6 +1,7 @@
 """The drop-in Python surface on the GPU: module functions with the reference's signatures,
 CompressedRowData.appendRow, and the findDirichletPrior CLI (stdin TSV -> stdout line)."""
 import io
+import sys
 import logging
 
 import numpy as np
@@ -213,3 +214,35 @@ def test_statistics_files_merge_to_the_whole(tmp_path):
     whole.appendMatrix(X)
     a0 = st.cli_init_alphas().cpu().numpy().tolist()
     assert DME.findDirichletPriors(merged, a0, 50) == DME.findDirichletPriors(whole, a0, 50)
+
+
+def test_cli_streams_stdin_in_pieces(monkeypatch):
+    """stdin is parsed and counted piece by piece (bounded memory): many small pieces give the same
+    statistics as one; a piece outside the fast parser's grammar hands the rest of the input to the
+    reference's row loop, quoting and errors included."""
+    from bayespy_amd import findDirichletPrior as cli
+    fx = load_golden("dirmult_k50")
+    X = fx["X"][:700]
+    text = "\n".join("\t".join(map(str, r)) for r in X.tolist())  # no trailing newline
+    whole, n_whole = cli.load_data(io.StringIO(text), fx["K"], 1.0, sys.maxsize, "\t")
+    monkeypatch.setattr(cli, "_CHUNK_BYTES", 1000)
+    pieces, n_pieces = cli.load_data(_Binary(text), fx["K"], 1.0, sys.maxsize, "\t")
+    assert n_whole == n_pieces == 700
+    assert pieces.U == whole.U and pieces.V == whole.V
+    # a quoted cell half-way: legal for csv.reader, outside the strict grammar
+    lines = text.split("\n")
+    cells = lines[400].split("\t")
+    lines[400] = '"' + cells[0] + '"\t' + "\t".join(cells[1:])
+    quoted, n_q = cli.load_data(_Binary("\n".join(lines) + "\n"), fx["K"], 1.0, sys.maxsize, "\t")
+    assert n_q == 700 and quoted.U == whole.U and quoted.V == whole.V
+    # a cell that is not a number: ValueError from int(), as in the reference
+    lines[500] = "x" + lines[500]
+    with pytest.raises(ValueError):
+        cli.load_data(_Binary("\n".join(lines) + "\n"), fx["K"], 1.0, sys.maxsize, "\t")
+
+
+class _Binary:
+    """A text stream with a .buffer, like sys.stdin."""
+
+    def __init__(self, text):
+        self.buffer = io.BytesIO(text.encode())
