@@ -12,7 +12,11 @@ around the CSR statistics entry (dme_stats_csr_i32) and the rest of the pipeline
   seed 20260004 (+ rank);  colidx int32, vals int32, rowptr int64
 
   python benchmarks/bow_csr.py [--rows 1000000] [--k 50000] [--steps 5] [--solve]
-Prints one JSON line: nnz, algorithmic bytes (nnz*8 + (N+1)*8), ms and GB/s of the statistics pass.
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+      benchmarks/bow_csr.py --rows 12500000 --solve      # the full configuration: 100M rows on 8 GPUs
+Prints one JSON line (rank 0): nnz, algorithmic bytes (nnz*8 + (N+1)*8), ms and GB/s of the
+statistics pass of one rank; with several ranks also the time of the whole estimation (statistics,
+all-reduce, scan, solve; max over ranks).
 """
 import argparse
 import json
@@ -101,12 +105,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--solve", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true")
+    ap.add_argument("--backend", default="nccl")
     args = ap.parse_args()
     import torch
+    import torch.distributed as dist
     from bayespy_amd import device as dev
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+
     t0 = time.time()
-    rowptr, colidx, vals = generate(args.rows, args.k, shuffle_columns=not args.no_shuffle)
+    rowptr, colidx, vals = generate(args.rows, args.k, seed=20260004 + rank,
+                                    shuffle_columns=not args.no_shuffle)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     N = rowptr.numel() - 1
@@ -116,6 +134,10 @@ def main():
     cs[1:] = torch.cumsum(vals.to(torch.int64), 0)
     max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
     del cs
+    if world > 1:  # every rank sizes its histograms alike: one collective per estimation
+        b = torch.tensor([max_count, max_total], dtype=torch.int64, device=vals.device)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        max_count, max_total = (int(x) for x in b.cpu())
     algo = nnz * 8 + (N + 1) * 8
 
     def one():
@@ -134,6 +156,24 @@ def main():
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
     info = st.check()
+    if world > 1:
+        # the whole estimation, all ranks: statistics -> all-reduce -> scan -> replicated solve
+        whole = []
+        for _ in range(args.steps):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stw = dev.DeviceStats(args.k, max_count, max_total)
+            stw.add_csr(rowptr, colidx, vals, max_count=max_count, max_total=max_total)
+            stw.allreduce(same_extents=True)
+            uvw = stw.finalize()
+            outw = uvw.solve(stw.cli_init_alphas(), 50, 0.0, trace_alphas=False)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=vals.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            whole.append(float(t.cpu()[0]))
+        rows_all = torch.tensor([N], dtype=torch.int64, device=vals.device)
+        dist.all_reduce(rows_all)
     line = {"workload": "bag-of-words CSR (BASELINE configs[3], one GPU's shard)", "K": args.k,
             "rows": N, "nnz": nnz, "max_count": max_count, "max_total": max_total,
             "algorithmic_bytes": algo, "stats_ms": sum(ms) / len(ms), "stats_ms_min": min(ms),
@@ -147,7 +187,16 @@ def main():
         line["finalize_solve_ms"] = (time.perf_counter() - t0) * 1e3
         line["solver"] = {"iterations": out["n_iters"], "loss_evals": out["n_evals"],
                           "exit": out["exit"], "final_loss": out["final_loss"]}
-    print(json.dumps(line))
+    if world > 1:
+        line["n_gpus"] = world
+        line["rows_all_ranks"] = int(rows_all.cpu()[0])
+        line["estimation_ms_all_ranks"] = min(whole) * 1e3
+        line["rows_per_s_all_ranks"] = int(rows_all.cpu()[0]) / min(whole)
+        line["rows_checked_all_ranks"] = stw.check()["rows"]
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
