@@ -394,3 +394,33 @@ def test_packed_int32_kernel_exceptions(oracle):
         bad.add_dense(_to_dev(Xn, "i32"), max_count=200000, max_total=int(X.sum(axis=1).max()))
         with pytest.raises(ValueError, match="negative"):
             bad.check()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_csr_partitioned_fuzz_vs_oracle(oracle, seed):
+    """Random CSR shapes through the partitioned pass against the oracle: K from one bucket to
+    thousands of buckets, empty rows, rows longer than a scatter batch, duplicate-free columns."""
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.choice([37, 256, 257, 5000, 70_000, 300_000]))
+    N = int(rng.integers(2000, 9000))
+    mean_len = int(rng.choice([3, 15, 40]))
+    lens = rng.poisson(mean_len, size=N)
+    lens[rng.random(N) < 0.1] = 0
+    if K >= 5000:
+        lens[int(rng.integers(0, N))] = 3000          # one row longer than a 2048-entry batch
+    lens = np.minimum(lens, K)
+    while lens.sum() < 40_000:                          # stay on the partitioned path
+        lens = np.minimum(lens * 2 + 1, K)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([rng.choice(K, size=l, replace=False) if l else np.zeros(0, dtype=np.int64)
+                          for l in lens]).astype(np.int32)
+    val = rng.geometric(0.4, size=col.size).astype(np.int32)
+    val[rng.random(col.size) < 0.01] = rng.integers(60, 500)
+    val[rng.random(col.size) < 0.02] = 0
+    st = dev.DeviceStats(K)
+    st.add_csr(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda())
+    assert st.check()["rows"] == N
+    ref = oracle.append_rows_csr(rowptr, col, val, K)
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
