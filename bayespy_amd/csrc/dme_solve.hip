@@ -640,15 +640,25 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
                 if (gk < 0.0) r = fmin(r, __ddiv_rn(w.alpha_cur[k], -gk));
             }
             r = __dmul_rn(block_min_f64(r, sh), 1.000000001);
-            while (__dmul_rn(learnRate, 0.9) > r) learnRate = __dmul_rn(learnRate, 0.9);
-            bool ok;
-            do {
+            // (a rate that no longer shrinks - the smallest denormal times 0.9 rounds back to itself -
+            // ends both loops: every wave must leave this kernel)
+            while (__dmul_rn(learnRate, 0.9) > r && __dmul_rn(learnRate, 0.9) < learnRate)
                 learnRate = __dmul_rn(learnRate, 0.9);
+            bool ok;
+            bool stuck = false;
+            do {
+                const double next = __dmul_rn(learnRate, 0.9);
+                stuck = !(next < learnRate);
+                learnRate = next;
                 for (long long k = tid; k < K; k += STEP_BLOCK)
                     w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __dmul_rn(w.g_cur[k], learnRate));
                 __syncthreads();
                 ok = finish_trial(c, w.alpha_trial, K, sh);
-            } while (!ok);
+            } while (!ok && !stuck);
+            if (!ok) {  // the reference would loop forever here (an infinite gradient component)
+                finish(0, DME_ERR_INTERNAL);
+                return;
+            }
             store_state(PH_HALVING);
             return;
         }
