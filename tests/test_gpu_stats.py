@@ -86,7 +86,9 @@ def test_padded_rows_and_offsets(oracle):
     """ld > K and a base pointer that is only element-aligned (narrower vector loads)."""
     dev = _dev()
     rng = np.random.default_rng(5)
-    for K, ld, off in [(1000, 1008, 0), (1000, 1003, 0), (100, 100, 1), (20, 24, 2), (50, 64, 3)]:
+    for K, ld, off in [(1000, 1008, 0), (1000, 1003, 0), (100, 100, 1), (20, 24, 2), (50, 64, 3),
+                       # int32: packed kernel (16-byte rows, K % 8 == 0) and its neighbours
+                       (1000, 1000, 2), (1024, 1028, 0), (512, 516, 4), (4096, 4100, 0), (1000, 1002, 0)]:
         N = 300
         big = rng.integers(0, 40, size=(N, ld)) * (rng.random((N, ld)) < 0.2)
         for dtype, npdt in (("u16", np.uint16), ("i32", np.int32)):
