@@ -19,6 +19,7 @@
 // (~1.5 us on MI355X) is cheaper than an in-kernel grid barrier (~4-7 us), which is why the loop is
 // a chain of launches and not one persistent kernel.  No MFMA: nothing here is a dense contraction.
 #include <math.h>
+#include <stdlib.h>
 
 #include "dme_common.h"
 
@@ -30,6 +31,7 @@ constexpr int SEG = 256;         // terms per segment: 4 per lane
 #endif
 constexpr int STEP_BLOCK = DME_STEP_BLOCK;
 constexpr int STEP_WAVES = STEP_BLOCK / 64;
+constexpr long long SMALL_NSEG = 64;  // at most this many segments: the single-launch solver
 constexpr int EVAL_BLOCK = 256;
 
 enum Phase : long long { PH_INIT = 0, PH_NEWTON = 1, PH_LOGSPACE = 2, PH_HALVING = 3, PH_EVALONLY = 4 };
@@ -307,15 +309,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void build_segments_kernel(
 // ---------------------------------------------------------------------------------------------
 // evaluation: one wave per segment
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(
+// Segments s = wave0, wave0 + nwaves, ... of the trial point: the three partial sums of each.
+__device__ __forceinline__ void eval_segments(
     const Ctrl* ctrl, const int* seg_k, const int* seg_start, const double* Uf, long long ldU,
     const long long* lenU, const double* Vf, long long capV, const long long* lenV, long long K,
-    const double* alpha, Partial* part) {
+    const double* alpha, Partial* part, long long wave0, long long nwaves) {
     if (ctrl->done || !ctrl->trial_valid) return;
     const int lane = threadIdx.x & 63;
     const long long nseg = ctrl->nseg;
-    const long long wave0 = ((long long)blockIdx.x * EVAL_BLOCK + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * EVAL_BLOCK) >> 6;
     for (long long s = wave0; s < nseg; s += nwaves) {
         const long long k = seg_k[s];
         const long long st = seg_start[s];
@@ -342,6 +343,15 @@ __global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(
             part[s] = p;
         }
     }
+}
+
+__global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(
+    const Ctrl* ctrl, const int* seg_k, const int* seg_start, const double* Uf, long long ldU,
+    const long long* lenU, const double* Vf, long long capV, const long long* lenV, long long K,
+    const double* alpha, Partial* part) {
+    eval_segments(ctrl, seg_k, seg_start, Uf, ldU, lenU, Vf, capV, lenV, K, alpha, part,
+                  ((long long)blockIdx.x * EVAL_BLOCK + threadIdx.x) >> 6,
+                  ((long long)gridDim.x * EVAL_BLOCK) >> 6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,13 +558,14 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
     finish_trial(w.ctrl, w.alpha_trial, K, sh);
 }
 
+// One round of the state machine of findDirichletPriors: consumes the evaluation of the trial
+// point, decides, and leaves the next trial point (or the result).  Called by every thread of a
+// STEP_BLOCK workgroup.
 template <bool CPT>
-__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, long long iterations,
-                                                          Prior pr, double* trace,
-                                                          double* trace_alpha, long long trace_cap,
-                                                          double* alpha_out, long long* result,
-                                                          double* final_loss) {
-    __shared__ BlockShared sh;
+__device__ void step_body(const Ws& w, long long K, long long iterations, const Prior& pr,
+                          double* trace, double* trace_alpha, long long trace_cap,
+                          double* alpha_out, long long* result, double* final_loss,
+                          BlockShared& sh) {
     Ctrl* c = w.ctrl;
     if (c->done) return;
     const int tid = threadIdx.x;
@@ -710,6 +721,59 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
         w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __ddiv_rn(__dsub_rn(bb, w.g_cur[k]), w.d_cur[k]));
     finish_trial(c, w.alpha_trial, K, sh);
     store_state(PH_NEWTON);
+}
+
+template <bool CPT>
+__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, long long iterations,
+                                                          Prior pr, double* trace,
+                                                          double* trace_alpha, long long trace_cap,
+                                                          double* alpha_out, long long* result,
+                                                          double* final_loss) {
+    __shared__ BlockShared sh;
+    step_body<CPT>(w, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
+                   final_loss, sh);
+}
+
+// Small problems (a few dozen segments: the reference's sample files, K = 2 Beta-binomial data):
+// the whole loop in ONE launch.  The workgroup's eight waves evaluate the segments, a barrier,
+// the same step_body, a barrier, and again - the arithmetic and its order are those of the
+// eval_kernel / step_kernel chain, whose ~10 us per round was launch overhead on such inputs.
+struct EvalArgs {
+    const double* Uf;
+    long long ldU;
+    const long long* lenU;
+    const double* Vf;
+    long long capV;
+    const long long* lenV;
+};
+
+template <bool CPT>
+__global__ __launch_bounds__(STEP_BLOCK) void small_solve_kernel(Ws w, EvalArgs e, long long K,
+                                                                 long long iterations, Prior pr,
+                                                                 double* trace, double* trace_alpha,
+                                                                 long long trace_cap,
+                                                                 double* alpha_out, long long* result,
+                                                                 double* final_loss,
+                                                                 long long max_rounds) {
+    __shared__ BlockShared sh;
+    const long long wave = threadIdx.x >> 6;
+    for (long long round = 0;; ++round) {
+        eval_segments(w.ctrl, w.seg_k, w.seg_start, e.Uf, e.ldU, e.lenU, e.Vf, e.capV, e.lenV, K,
+                      w.alpha_trial, w.part, wave, STEP_WAVES);
+        __syncthreads();
+        step_body<CPT>(w, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
+                       final_loss, sh);
+        __syncthreads();
+        if (((volatile Ctrl*)w.ctrl)->done) break;
+        if (round >= max_rounds) {  // cannot happen for finite inputs; every wave must leave
+            if (threadIdx.x == 0) {
+                w.ctrl->done = 1;
+                result[3] = DME_ERR_INTERNAL;
+                result[6] = 1;
+            }
+            break;
+        }
+    }
 }
 
 // dme_eval epilogue: publish the evaluated quantities
@@ -907,6 +971,24 @@ int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double*
     if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
     long long done = 0;
     const bool cpt = pr.beta != nullptr || pr.has_W;
+    long long small_nseg = SMALL_NSEG;
+    if (const char* e = getenv("DME_SOLVE_SMALL_NSEG")) small_nseg = atoll(e);  // test hook: 0 = never
+    if (w.nseg_max <= small_nseg) {
+        const EvalArgs ea{Uf, (long long)ldU, (const long long*)lenU, Vf, (long long)capV,
+                          (const long long*)lenV};
+        if (cpt)
+            hipLaunchKernelGGL(small_solve_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
+                               (long long)K, (long long)iterations, pr, trace, trace_alpha,
+                               (long long)trace_cap, alpha, (long long*)result, final_loss, max_pairs);
+        else
+            hipLaunchKernelGGL(small_solve_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
+                               (long long)K, (long long)iterations, pr, trace, trace_alpha,
+                               (long long)trace_cap, alpha, (long long*)result, final_loss, max_pairs);
+        DME_HIP_CHECK(hipGetLastError());
+        DME_HIP_CHECK(hipMemcpyAsync(pinned, result, 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
+        DME_HIP_CHECK(hipStreamSynchronize(s));
+        done = 1;
+    }
     while (!done) {
         for (int i = 0; i < batch; ++i) {
             hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, w.ctrl, w.seg_k,

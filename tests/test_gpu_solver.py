@@ -129,3 +129,27 @@ def test_zero_iterations_returns_init():
     out = uv.solve([0.5, 0.25], 0, 0.0)
     assert out["exit"] == 3 and out["n_iters"] == 0
     assert out["alpha"].tolist() == [0.5, 0.25]
+
+
+def test_single_launch_and_chained_solvers_agree_bit_for_bit(monkeypatch):
+    """Small problems run the whole loop in one launch, larger ones as a chain of eval / step
+    launches: same device functions, same order of operations, so the same bits - checked on every
+    golden solve small enough for the single launch, all branches and exits included."""
+    from bayespy_amd import device
+    n = 0
+    for name in GOLDEN_CASES:
+        fx = load_golden(name)
+        uv = _uv(fx)
+        for s in fx["solves"]:
+            if s["variant"] != "DE" or "raises" in s:
+                continue
+            monkeypatch.setenv("DME_SOLVE_SMALL_NSEG", "1000000")
+            a = uv.solve(s["init"], s["iterations"], s["hyperprior"])
+            monkeypatch.setenv("DME_SOLVE_SMALL_NSEG", "0")
+            b = uv.solve(s["init"], s["iterations"], s["hyperprior"])
+            assert a["exit"] == b["exit"] and a["n_iters"] == b["n_iters"] and a["n_evals"] == b["n_evals"]
+            assert np.array_equal(a["alpha"], b["alpha"]), (name, s["init_name"])
+            assert np.array_equal(a["trace"], b["trace"])
+            assert a["final_loss"] == b["final_loss"]
+            n += 1
+    assert n >= 10
