@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric on BASELINE.json's config.
 
-metric : count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows), whole job
+metric : count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows) at 1/2/4/8 GPUs, whole job
+         (BASELINE.json's metric string, verbatim)
 workload: configs[2] = "K=1000 synthetic Dirichlet-multinomial, 10M rows, row totals 1-500"
           (SURVEY 8d C3): uint16 dense rows resident in HBM, alpha_true = 0.01 + Gamma(2, 0.05)
           (numpy seed 0), n_i ~ UniformInt[1, 500], x_i ~ DirichletMultinomial(n_i, alpha_true),
@@ -154,7 +155,7 @@ def main():
             traffic = None
 
     line = {
-        "metric": "count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows)",
+        "metric": "count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows) at 1/2/4/8 GPUs",
         "value": value,
         "unit": "rows/s",
         "n_gpus": world,
