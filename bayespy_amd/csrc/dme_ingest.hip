@@ -45,6 +45,12 @@ int parse_chunk(const char* b, const char* e, char delim, long long K, int32_t* 
     const char* p = b;
     while (p < e) {
         for (long long k = 0; k < K; ++k) {
+            // count matrices are mostly one-digit cells: "d<delim>" takes this short cut
+            if (k + 1 < K && e - p >= 2 && (unsigned)(p[0] - '0') <= 9u && p[1] == delim) {
+                *o++ = p[0] - '0';
+                p += 2;
+                continue;
+            }
             while (p < e && *p == ' ') ++p;
             bool neg = false;
             if (p < e && (*p == '+' || *p == '-')) { neg = (*p == '-'); ++p; }
