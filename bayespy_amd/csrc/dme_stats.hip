@@ -231,7 +231,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                 if constexpr (MULTI) {
                     u32 incl = s;
 #pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) {
+                    for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
                         u32 up = __shfl_up(incl, dd);
                         if (c >= dd) incl += up;
                     }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                     if constexpr (MULTI) {
                         u32 incl = s32;
 #pragma unroll
-                        for (int dd = 1; dd < 64; dd <<= 1) {
+                        for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
                             u32 up = __shfl_up(incl, dd);
                             if (c >= dd) incl += up;
                         }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                     if constexpr (MULTI) {
                         u64 incl = s;
 #pragma unroll
-                        for (int dd = 1; dd < 64; dd <<= 1) {
+                        for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
                             u64 up = __shfl_up(incl, dd);
                             if (c >= dd) incl += up;
                         }
