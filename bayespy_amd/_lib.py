@@ -37,6 +37,9 @@ SIGNATURES = {
     "dme_stats_dense_weighted_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dme_suffix_scan_weighted": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "dme_cli_init_alphas": (_int, [_vp, _i64, _vp, _vp]),
+    "dme_shard_message_words": (_i64, [_i64, _i64, _i64, _i64]),
+    "dme_shard_pack": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_shard_unpack": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "dme_solver_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "dme_eval": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dme_predicted_step": (_int, [_f64, _vp, _vp, _i64, _vp, _vp, _vp]),

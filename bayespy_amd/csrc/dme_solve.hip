@@ -256,11 +256,10 @@ __device__ __forceinline__ bool block_any(bool p, BlockShared& sh) {
 // ---------------------------------------------------------------------------------------------
 // segment table: column k (k == K is V) gets ceil(len_k / SEG) segments, listed in column order
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(STEP_BLOCK) void build_segments_kernel(
+__device__ void build_segments(
     Ctrl* ctrl, const long long* lenU, const long long* lenV, long long K, long long ldU,
     long long capV, int* seg_k, int* seg_start, long long* segfirst, long long nseg_max) {
     __shared__ long long wsum[STEP_WAVES];
-    __shared__ long long base_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long ncol = K + 1;
     const long long per = (ncol + STEP_BLOCK - 1) / STEP_BLOCK;
@@ -303,7 +302,6 @@ __global__ __launch_bounds__(STEP_BLOCK) void build_segments_kernel(
         segfirst[ncol] = total;
         ctrl->nseg = total < nseg_max ? total : nseg_max;
     }
-    (void)base_sh;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -543,10 +541,14 @@ __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
     return !bad;
 }
 
+// Segment table of the statistics (build_segments) and the start state of the loop, one launch.
 __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* alpha, long long K,
-                                                           long long phase) {
+                                                           long long phase, const long long* lenU,
+                                                           const long long* lenV, long long ldU,
+                                                           long long capV) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x;
+    build_segments(w.ctrl, lenU, lenV, K, ldU, capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
     if (tid == 0) {
         Ctrl* c = w.ctrl;
         c->done = 0; c->phase = phase; c->count = 0; c->n_evals = 0; c->exit_reason = 0;
@@ -878,10 +880,8 @@ int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
     DME_REQUIRE(alpha && out_scalars, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, alpha, (long long)K,
-                       (long long)PH_EVALONLY);
-    hipLaunchKernelGGL(build_segments_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w.ctrl,
-                       (const long long*)lenU, (const long long*)lenV, (long long)K, (long long)ldU,
-                       (long long)capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
+                       (long long)PH_EVALONLY, (const long long*)lenU, (const long long*)lenV,
+                       (long long)ldU, (long long)capV);
     // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
     hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
                        w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
@@ -954,19 +954,23 @@ int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double*
     hipStream_t s = (hipStream_t)stream;
     DME_HIP_CHECK(hipMemsetAsync(result, 0, 8 * sizeof(int64_t), s));
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)alpha,
-                       (long long)K, (long long)PH_INIT);
-    hipLaunchKernelGGL(build_segments_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w.ctrl,
-                       (const long long*)lenU, (const long long*)lenV, (long long)K, (long long)ldU,
-                       (long long)capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
+                       (long long)K, (long long)PH_INIT, (const long long*)lenU,
+                       (const long long*)lenV, (long long)ldU, (long long)capV);
     DME_HIP_CHECK(hipGetLastError());
     const unsigned grid = eval_grid(w.nseg_max);
     // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
     const long long max_pairs = (iterations + 2) * 450 + 16;
     long long pairs = 0;
     // Typical solves take 5-15 evaluations.  The first batch is enqueued while earlier work on the
-    // stream (the statistics pass) still runs, so its launches cost the host nothing and a launch
-    // pair that finds the solve finished costs ~3 us of device time: make it cover most solves.
+    // stream (the statistics pass) still runs, so its launches cost the host nothing, but a launch
+    // pair that finds the solve finished still costs ~9 us of device time and a batch that falls
+    // short costs a host round trip (~25 us).  Solves come in series on similar statistics (EM
+    // rounds, re-estimation as rows arrive, the steps of a benchmark): the first batch covers what
+    // this thread's previous solve of the same shape needed plus one pair, 16 pairs otherwise.
+    static thread_local long long hint_K = -1, hint_ldU = -1, hint_pairs = 0;
     int batch = 16;
+    if (hint_K == K && hint_ldU == ldU && hint_pairs > 0)
+        batch = (int)(hint_pairs + 1 < 4 ? 4 : (hint_pairs + 1 > 32 ? 32 : hint_pairs + 1));
     long long* pinned = poll_buffer();
     if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
     long long done = 0;
@@ -1015,6 +1019,9 @@ int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double*
         batch = pairs < 64 ? 8 : 32;
     }
     const long long* res = pinned;  // the last poll already brought the whole result block
+    hint_K = K;
+    hint_ldU = ldU;
+    hint_pairs = res[4];  // launch pairs that did work
     if (result_host)
         for (int i = 0; i < 8; ++i) result_host[i] = res[i];
     if (res[3] == DME_ERR_ZERO_DIVISION)

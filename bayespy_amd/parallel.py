@@ -42,13 +42,16 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
 
-    One integer SUM carries everything: hist || histV || the additive status words || one
-    slot per rank for its two observed maxima || one slot per rank for the bit patterns of its K
-    mean accumulators.  A rank fills only its own slots, so the sum hands every rank all the
-    per-rank values unchanged; the maxima are then taken locally and the fp64 accumulators are
-    added in rank order, which makes the start point of the replicated solve identical on every
-    rank and from run to run.  `same_extents` (every rank built its histograms with the same
-    max_count / max_total) skips the MAX all-reduce that otherwise agrees the extents first."""
+    One integer SUM carries everything (layout of include/dme_hip.h, dme_shard_pack):
+    hist || histV || status[8] (the two maxima, [4:6], as 0) || one slot row per rank for its two
+    observed maxima and the bit patterns of its K mean accumulators.  A rank fills only its own
+    slot row, so the sum hands every rank all the per-rank values unchanged; the maxima are then
+    taken locally and the fp64 accumulators are added in rank order, which makes the start point of
+    the replicated solve identical on every rank and from run to run.  On the GPU the message is
+    written and read by two HIP kernels (dme_shard_pack / dme_shard_unpack); host tensors (the
+    gloo tests) build the same message with torch.  `same_extents` (every rank built its histograms
+    with the same max_count / max_total) skips the MAX all-reduce that otherwise agrees the
+    extents first."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return hist, histV, status, init_acc, nbins, tbins
@@ -60,24 +63,38 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
         nb, tb = (int(v) for v in ext.cpu())
         hist = grow_hist(hist, K, nbins, nb)
         histV = grow_vec(histV, tb)
-    slots = torch.zeros(world, 2 + K, dtype=torch.int64, device=hist.device)
+    nh, nv = hist.numel(), histV.numel()
+    nmsg = nh + nv + 8 + world * (2 + K)
+    if hist.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        L = _lib.lib()
+        with _on(hist.device):
+            msg = torch.empty(nmsg, dtype=torch.int64, device=hist.device)
+            _lib.check(L.dme_shard_pack(_ptr(hist), nh, _ptr(histV), nv, _ptr(status),
+                                        _ptr(init_acc), K, rank, world, _ptr(msg), _stream()))
+            if dist.get_backend(group) == "gloo":
+                # rehearsals with several gloo ranks on one card: gloo's staged copy of a device
+                # tensor was seen to hang when issued behind a long-running kernel of the same
+                # process; RCCL ("nccl") orders itself on the stream and needs no host sync
+                torch.cuda.current_stream(msg.device).synchronize()
+            dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+            acc = torch.empty(K, dtype=torch.float64, device=hist.device)
+            _lib.check(L.dme_shard_unpack(_ptr(msg), nh, nv, K, world, _ptr(acc), _stream()))
+        return msg[:nh], msg[nh:nh + nv], msg[nh + nv:nh + nv + 8], acc, nb, tb
+    msg = torch.zeros(nmsg, dtype=torch.int64)
+    msg[:nh] = hist
+    msg[nh:nh + nv] = histV
+    msg[nh + nv:nh + nv + 8] = status
+    msg[nh + nv + 4:nh + nv + 6] = 0  # the maxima travel in the slots
+    slots = msg[nh + nv + 8:].view(world, 2 + K)
     slots[rank, :2] = status[4:6]
     slots[rank, 2:] = init_acc.view(torch.int64)
-    flat = torch.cat([hist, histV, status[:4], status[6:8], slots.view(-1)])  # [4:6] are maxima
-    if flat.is_cuda and dist.get_backend(group) == "gloo":
-        # rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor
-        # was seen to hang when issued behind a long-running kernel of the same process; RCCL
-        # ("nccl") orders itself on the stream and needs no host sync
-        torch.cuda.current_stream(flat.device).synchronize()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    nh, nv = hist.numel(), histV.numel()
-    slots = flat[nh + nv + 6:].view(world, 2 + K)
-    out_status = torch.zeros_like(status)
-    out_status[:4] = flat[nh + nv:nh + nv + 4]
-    out_status[6:8] = flat[nh + nv + 4:nh + nv + 6]
+    dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+    out_status = msg[nh + nv:nh + nv + 8]
     out_status[4:6] = slots[:, :2].max(dim=0).values
     parts = slots[:, 2:].contiguous().view(torch.float64)
     acc = parts[0].clone()
     for r in range(1, world):  # fixed order: bit-identical on every rank
         acc += parts[r]
-    return flat[:nh], flat[nh:nh + nv], out_status, acc, nb, tb
+    return msg[:nh], msg[nh:nh + nv], out_status, acc, nb, tb

@@ -135,6 +135,27 @@ int dme_cli_init_alphas(const double* init_acc /*[dev]*/, int64_t K, double* alp
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: rows shard over GPUs and the value histograms of disjoint row sets add exactly
+ * (they are sums of the per-row terms of DE/dme.py:116-123; the reference itself is one process).
+ * ONE integer SUM all-reduce (RCCL, issued by the caller: torch.distributed) carries the message
+ *     msg = hist[nh] | histV[nv] | status[8] | slots[world][2 + K]          (64-bit words)
+ * dme_shard_pack writes a rank's message: its histograms, its additive status words (status[4],
+ * status[5] - the observed maxima - as 0) and, in its own slot row only, the two maxima and the
+ * bit patterns of its K fp64 mean accumulators (DE/fdp.py:87-89); other ranks' slot rows are 0, so
+ * the sum hands every rank all slot rows unchanged.  dme_shard_unpack, after the all-reduce, sets
+ * status[4], status[5] inside msg to the maxima over ranks and writes init_acc[k] = the ranks'
+ * accumulators added in rank order (bit-identical on every rank).  hist / histV / status are then
+ * read in place from msg.  dme_shard_message_words = nh + nv + 8 + world*(2 + K).
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_shard_message_words(int64_t nh, int64_t nv, int64_t K, int64_t world);
+int dme_shard_pack(const uint64_t* hist /*[dev]*/, int64_t nh, const uint64_t* histV /*[dev]*/,
+                   int64_t nv, const uint64_t* status /*[dev][8]*/,
+                   const double* init_acc /*[dev][K]*/, int64_t K, int64_t rank, int64_t world,
+                   uint64_t* msg /*[dev]*/, void* stream);
+int dme_shard_unpack(uint64_t* msg /*[dev]*/, int64_t nh, int64_t nv, int64_t K, int64_t world,
+                     double* init_acc /*[dev][K] out*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Solver.  U is dense-padded fp64: U[k][n] = Uf[k*ldU + n] for n < lenU[k]; V = Vf[0..lenV).
  * lenU [K] and lenV [1] are device arrays (as written by dme_suffix_scan).
  * workspace: dme_solver_workspace_bytes(K, ldU, capV) bytes [dev], 256-byte aligned, where
