@@ -56,3 +56,60 @@ def test_two_ranks_allreduce_then_identical_solve():
         np.testing.assert_allclose(alpha, ref["final"], rtol=1e-9)
         assert n_iters == ref["n_iters"]
     assert np.array_equal(out[0][3], out[1][3])  # replicated solve: bit-identical on every rank
+
+
+@pytest.mark.parametrize("world,K,nbins,tbins", [(3, 5, 4, 7), (8, 1000, 33, 65), (2, 1, 2, 2)])
+def test_shard_message_kernels_match_the_host_layout(world, K, nbins, tbins):
+    """dme_shard_pack / dme_shard_unpack against the message the host code builds for gloo ranks
+    (bayespy_amd/parallel.py): every rank's packed message word for word; then, on the summed
+    message, the maxima over ranks and the accumulators added in rank order, bit for bit."""
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(world * 1000 + K)
+    nh, nv = K * nbins, tbins
+    nmsg = nh + nv + 8 + world * (2 + K)
+    assert L.dme_shard_message_words(nh, nv, K, world) == nmsg
+    stream = torch.cuda.current_stream().cuda_stream
+    total = np.zeros(nmsg, dtype=np.int64)
+    accs, stats = [], []
+    for rank in range(world):
+        hist = rng.integers(0, 1 << 40, size=nh, dtype=np.int64)
+        histV = rng.integers(0, 1 << 40, size=nv, dtype=np.int64)
+        status = rng.integers(0, 1 << 30, size=8, dtype=np.int64)
+        acc = rng.random(K) * 10.0 ** rng.integers(-8, 8, size=K)
+        accs.append(acc)
+        stats.append(status)
+        want = np.zeros(nmsg, dtype=np.int64)
+        want[:nh], want[nh:nh + nv] = hist, histV
+        want[nh + nv:nh + nv + 8] = status
+        want[nh + nv + 4:nh + nv + 6] = 0
+        slots = want[nh + nv + 8:].reshape(world, 2 + K)
+        slots[rank, :2] = status[4:6]
+        slots[rank, 2:] = acc.view(np.int64)
+        d = [torch.from_numpy(a).cuda() for a in (hist, histV, status, acc)]
+        msg = torch.full((nmsg,), -1, dtype=torch.int64, device="cuda")
+        _lib.check(L.dme_shard_pack(d[0].data_ptr(), nh, d[1].data_ptr(), nv, d[2].data_ptr(),
+                                    d[3].data_ptr(), K, rank, world, msg.data_ptr(), stream))
+        assert np.array_equal(msg.cpu().numpy(), want)
+        total += want
+    msg = torch.from_numpy(total).cuda()
+    out = torch.empty(K, dtype=torch.float64, device="cuda")
+    _lib.check(L.dme_shard_unpack(msg.data_ptr(), nh, nv, K, world, out.data_ptr(), stream))
+    got = msg.cpu().numpy()
+    st = got[nh + nv:nh + nv + 8]
+    summed = np.sum(stats, axis=0)
+    assert np.array_equal(st[:4], summed[:4]) and np.array_equal(st[6:], summed[6:])
+    assert st[4] == max(s[4] for s in stats) and st[5] == max(s[5] for s in stats)
+    ref = accs[0].copy()
+    for r in range(1, world):
+        ref = ref + accs[r]
+    assert np.array_equal(out.cpu().numpy(), ref)  # rank order, bit for bit
+    assert np.array_equal(got[:nh + nv], total[:nh + nv])
+
+
+def test_shard_pack_rejects_bad_rank():
+    from bayespy_amd import _lib
+    z = torch.zeros(16, dtype=torch.int64, device="cuda")
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().dme_shard_pack(z.data_ptr(), 2, z.data_ptr(), 2, z.data_ptr(),
+                                             z.data_ptr(), 1, 3, 2, z.data_ptr(), 0))
