@@ -7,61 +7,160 @@
 //     histW[k][v] += weight for x_ik == v,   histVW[t] += weight for sum_k x_ik == t      (fp64)
 // and U/V are again reverse suffix sums.  len(U[k]) grows with every appended row whatever its
 // weight, so the largest count per column / largest total are tracked as integers beside the sums.
-// First version: one wave per row, fp64 global atomics (no LDS privatisation) — the callers of
-// this path hold thousands of rows, not billions.  fp64 sums here depend on arrival order in the
-// last bits (the reference adds row by row).
+// One wave per row.  Counts 1..B of every column and row totals below TB are privatised in LDS as
+// fp64 bins (ds_add_f64; a wave's lanes own distinct columns, so the adds do not collide), the
+// largest count per column as 32-bit LDS maxima; a workgroup adds its non-zero bins to the global
+// histograms once, at the end.  Counts above B and long totals go straight to fp64 global atomics
+// (they execute at the memory side, ~20 G/s chip-wide: the whole pass ran at that rate before the
+// bins were privatised).  C weight columns per row (the C components of the mixture EM,
+// CPT/dirichletMixtureEstimation.py:130-133) fill C histograms in the same pass over X.
+// fp64 sums here depend on arrival order in the last bits (the reference adds row by row).
 #include "dme_common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void stats_weighted_kernel(
-    const int* X, const double* wts, long long N, long long K, long long ld, double* histW,
-    long long nbins, double* histVW, long long tbins, long long* maxcol, long long* maxtot,
-    u64* status) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    u64 bad_cells = 0, bad_rows = 0, neg = 0, rows = 0;
-    for (long long i = wave0; i < N; i += nwaves) {
-        const int* row = X + i * ld;
-        const double w = wts[i];
-        u64 s = 0;
-        for (long long k = lane; k < K; k += 64) {
-            const int v = row[k];
-            s += (u64)(v > 0 ? v : 0);
+constexpr int WBLOCK = 1024;
+constexpr int WWAVES = WBLOCK / 64;
+constexpr long long W_LDS_BYTES = 150 * 1024;
+
+struct WArgs {
+    const int* X;
+    const double* wts;  // [N][C]
+    long long N, K, ld, C;
+    double* histW;   // [C][K][nbins]
+    long long nbins;
+    double* histVW;  // [C][tbins]
+    long long tbins;
+    long long* maxcol;
+    long long* maxtot;
+    u64* status;
+    int B;       // counts 1..B live in LDS
+    int TB;      // totals below TB live in LDS
+    int mxlds;   // column maxima in LDS (K small enough)
+    long long rows_per_wg;
+};
+
+// J > 0: a lane keeps its J cells of a row (columns lane + 64 j) in registers and the next row's
+// loads are in flight while the current row is processed; J == 0 (K > 1024): the row is read twice.
+template <int J>
+__global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
+    extern __shared__ double wl[];
+    const long long K = a.K, C = a.C;
+    const int B = a.B, TB = a.TB;
+    double* hv = wl;                              // [C][TB]
+    double* h = hv + C * TB;                      // [C][B][K]: count v of column k at ((c*B + v-1)*K + k)
+    u32* mx = (u32*)(h + C * (long long)B * K);   // [K] when mxlds
+    __shared__ u64 sh_stat[8];  // [1] cells >= nbins [2] totals >= tbins [3] negatives [5] max total
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long nd = C * TB + C * (long long)B * K;
+    for (long long i = tid; i < nd; i += WBLOCK) wl[i] = 0.0;
+    if (a.mxlds)
+        for (long long k = tid; k < K; k += WBLOCK) mx[k] = 0;
+    if (tid < 8) sh_stat[tid] = 0;
+    __syncthreads();
+    const long long row0 = (long long)blockIdx.x * a.rows_per_wg;
+    const long long row1 = row0 + a.rows_per_wg < a.N ? row0 + a.rows_per_wg : a.N;
+    u64 bad_cells = 0, bad_rows = 0, neg = 0;
+    constexpr int JR = J > 0 ? J : 1;
+    int cur[JR], nxt[JR];
+    auto load_row = [&](int (&d)[JR], long long i) {
+        if constexpr (J > 0) {
+            const int* row = a.X + i * a.ld;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const long long k = lane + 64 * j;
+                d[j] = (i < row1 && k < K) ? __builtin_nontemporal_load(row + k) : 0;
+            }
         }
-        const u64 total = dme_wave_sum_u64(s);
-        rows++;
+    };
+    auto total_of = [&](u64 total, const double* w) {
         if (lane == 0 && total > 0) {
-            if ((long long)total < tbins) {
-                atomicAdd(&histVW[total], w);
-                // the maxima settle after a few rows: look before paying for an atomic
-                if ((u64)__builtin_nontemporal_load(maxtot) < total) atomicMax((u64*)maxtot, total);
+            if ((long long)total < a.tbins) {
+                atomicMax(&sh_stat[5], total);
+                if (total < (u64)TB)
+                    for (long long c = 0; c < C; ++c) atomicAdd(&hv[c * TB + (long long)total], w[c]);
+                else
+                    for (long long c = 0; c < C; ++c) atomicAdd(&a.histVW[c * a.tbins + (long long)total], w[c]);
             } else {
                 bad_rows++;
             }
         }
-        for (long long k = lane; k < K; k += 64) {
-            const int v = row[k];
-            if (v == 0) continue;
-            if (v < 0) { neg++; continue; }
-            if ((long long)v < nbins) {
-                atomicAdd(&histW[k * nbins + v], w);
-                if (__builtin_nontemporal_load(&maxcol[k]) < (long long)v) atomicMax((u64*)&maxcol[k], (u64)v);
-            } else {
-                bad_cells++;
+    };
+    auto cell = [&](int v, long long k, const double* w) {
+        if (v == 0) return;
+        if (v < 0) { neg++; return; }
+        if ((long long)v >= a.nbins) { bad_cells++; return; }
+        if (a.mxlds) {
+            atomicMax(&mx[k], (u32)v);
+        } else if (__builtin_nontemporal_load(&a.maxcol[k]) < (long long)v) {
+            atomicMax((u64*)&a.maxcol[k], (u64)v);  // the maxima settle after a few rows
+        }
+        if (v <= B)
+            for (long long c = 0; c < C; ++c) atomicAdd(&h[(c * B + (v - 1)) * K + k], w[c]);
+        else
+            for (long long c = 0; c < C; ++c) atomicAdd(&a.histW[(c * K + k) * a.nbins + v], w[c]);
+    };
+    load_row(nxt, row0 + wave);
+    for (long long i = row0 + wave; i < row1; i += WWAVES) {
+        const double* w = a.wts + i * C;
+        if constexpr (J > 0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) cur[j] = nxt[j];
+            load_row(nxt, i + WWAVES);
+            u64 s = 0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) s += (u64)(cur[j] > 0 ? cur[j] : 0);
+            total_of(dme_wave_sum_u64(s), w);
+#pragma unroll
+            for (int j = 0; j < J; ++j) cell(cur[j], lane + 64 * j, w);
+        } else {
+            const int* row = a.X + i * a.ld;
+            u64 s = 0;
+            for (long long k = lane; k < K; k += 64) {
+                const int v = row[k];
+                s += (u64)(v > 0 ? v : 0);
             }
+            total_of(dme_wave_sum_u64(s), w);
+            for (long long k = lane; k < K; k += 64) cell(row[k], k, w);  // second read: L1 / L2
         }
     }
     bad_cells = dme_wave_sum_u64(bad_cells);
     bad_rows = dme_wave_sum_u64(bad_rows);
     neg = dme_wave_sum_u64(neg);
     if (lane == 0) {
-        if (rows) atomicAdd(&status[0], rows);
-        if (bad_cells) atomicAdd(&status[1], bad_cells);
-        if (bad_rows) atomicAdd(&status[2], bad_rows);
-        if (neg) atomicAdd(&status[3], neg);
+        if (bad_cells) atomicAdd(&sh_stat[1], bad_cells);
+        if (bad_rows) atomicAdd(&sh_stat[2], bad_rows);
+        if (neg) atomicAdd(&sh_stat[3], neg);
     }
+    __syncthreads();
+    // the workgroup's bins -> the global histograms (zero bins cost nothing)
+    const long long BK = (long long)B * K;
+    for (long long i = tid; i < C * BK; i += WBLOCK) {
+        const double x = h[i];
+        if (x != 0.0) {
+            const long long c = i / BK, rem = i - c * BK;
+            const long long vb = rem / K, k = rem - vb * K;
+            atomicAdd(&a.histW[(c * K + k) * a.nbins + vb + 1], x);
+        }
+    }
+    for (long long i = tid; i < C * TB; i += WBLOCK) {
+        const double x = hv[i];
+        if (x != 0.0) {
+            const long long c = i / TB, t = i - c * TB;
+            atomicAdd(&a.histVW[c * a.tbins + t], x);
+        }
+    }
+    if (a.mxlds)
+        for (long long k = tid; k < K; k += WBLOCK) {
+            const u64 m = mx[k];
+            if (m && (u64)a.maxcol[k] < m) atomicMax((u64*)&a.maxcol[k], m);
+        }
+    if (tid == 0) {
+        if (row1 > row0) atomicAdd(&a.status[0], (u64)(row1 - row0));
+        if (sh_stat[5] && (u64)a.maxtot[0] < sh_stat[5]) atomicMax((u64*)a.maxtot, sh_stat[5]);
+    }
+    if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
 }
 
 // Uf[k][n] += sum_{v > n} histW[k][v]; lenU[k] = max(lenU[k], maxcol[k]).  One thread per column
@@ -88,25 +187,78 @@ __global__ __launch_bounds__(256) void suffix_scan_weighted_kernel(
 
 }  // namespace
 
+namespace {
+
+int stats_weighted(const int32_t* X, const double* weights, int64_t C, int64_t N, int64_t K,
+                   int64_t ld, double* histW, int64_t nbins, double* histVW, int64_t tbins,
+                   int64_t* maxcol, int64_t* maxtot, uint64_t* status, void* stream) {
+    DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", (long long)N,
+                (long long)K, (long long)ld);
+    DME_REQUIRE(C >= 1 && C <= 64, "weight columns per row: 1..64, got %lld", (long long)C);
+    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
+    DME_REQUIRE(nbins <= 0xFFFFFFFFLL, "nbins too large");
+    DME_REQUIRE(histW && histVW && maxcol && maxtot && status, "null output pointer");
+    if (N == 0) return DME_OK;
+    DME_REQUIRE(X && weights, "null input pointer");
+    WArgs a{};
+    a.X = X; a.wts = weights; a.N = N; a.K = K; a.ld = ld; a.C = C;
+    a.histW = histW; a.nbins = nbins; a.histVW = histVW; a.tbins = tbins;
+    a.maxcol = (long long*)maxcol; a.maxtot = (long long*)maxtot; a.status = (u64*)status;
+    // LDS: column maxima (4 B each) when they fit in a quarter of the budget, then row-total bins
+    // (at most a quarter), the rest for count bins 1..B of every column and weight column
+    long long budget = W_LDS_BYTES;
+    a.mxlds = K * 4 <= budget / 4 ? 1 : 0;
+    if (a.mxlds) budget -= (K * 4 + 7) & ~7LL;
+    long long TB = tbins;
+    if (TB * C * 8 > budget / 4) TB = budget / 4 / (C * 8);
+    a.TB = (int)TB;
+    budget -= TB * C * 8;
+    long long B = budget / (C * K * 8);
+    if (B > nbins - 1) B = nbins - 1;
+    if (B < 0) B = 0;
+    a.B = (int)B;
+    const size_t lds = (size_t)(C * TB * 8 + C * B * K * 8 + (a.mxlds ? ((K * 4 + 7) & ~7LL) : 0));
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    // a workgroup should see enough rows to repay the flush of its bins
+    long long grid = (N + 255) / 256;
+    if (grid > cus) grid = cus;
+    if (grid < 1) grid = 1;
+    a.rows_per_wg = (N + grid - 1) / grid;
+    grid = (N + a.rows_per_wg - 1) / a.rows_per_wg;
+    auto launch = [&](auto kern) -> int {
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WBLOCK), lds, (hipStream_t)stream, a);
+        return DME_OK;
+    };
+    int rc;
+    if (K <= 128) rc = launch(stats_weighted_kernel<2>);
+    else if (K <= 256) rc = launch(stats_weighted_kernel<4>);
+    else if (K <= 1024) rc = launch(stats_weighted_kernel<16>);
+    else rc = launch(stats_weighted_kernel<0>);
+    if (rc) return rc;
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+}  // namespace
+
 extern "C" int dme_stats_dense_weighted_i32(const int32_t* X, const double* weights, int64_t N,
                                             int64_t K, int64_t ld, double* histW, int64_t nbins,
                                             double* histVW, int64_t tbins, int64_t* maxcol,
                                             int64_t* maxtot, uint64_t* status, void* stream) {
-    DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", (long long)N,
-                (long long)K, (long long)ld);
-    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
-    DME_REQUIRE(histW && histVW && maxcol && maxtot && status, "null output pointer");
-    if (N == 0) return DME_OK;
-    DME_REQUIRE(X && weights, "null input pointer");
-    int cus = dme_device_cus();
-    if (cus <= 0) cus = 256;
-    long long waves = N < (long long)cus * 16 ? N : (long long)cus * 16;
-    hipLaunchKernelGGL(stats_weighted_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, X, weights, (long long)N, (long long)K, (long long)ld,
-                       histW, (long long)nbins, histVW, (long long)tbins, (long long*)maxcol,
-                       (long long*)maxtot, (u64*)status);
-    DME_HIP_CHECK(hipGetLastError());
-    return DME_OK;
+    return stats_weighted(X, weights, 1, N, K, ld, histW, nbins, histVW, tbins, maxcol, maxtot,
+                          status, stream);
+}
+
+extern "C" int dme_stats_dense_weighted_batch_i32(const int32_t* X, const double* weights,
+                                                  int64_t C, int64_t N, int64_t K, int64_t ld,
+                                                  double* histW, int64_t nbins, double* histVW,
+                                                  int64_t tbins, int64_t* maxcol, int64_t* maxtot,
+                                                  uint64_t* status, void* stream) {
+    return stats_weighted(X, weights, C, N, K, ld, histW, nbins, histVW, tbins, maxcol, maxtot,
+                          status, stream);
 }
 
 extern "C" int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t nbins,

@@ -519,18 +519,26 @@ class DeviceStats:
 
 class WeightedStats:
     """fp64 value histograms of rows that carry a weight (appendRow(row, w), w != 1):
-    dme_stats_dense_weighted_i32 / dme_suffix_scan_weighted."""
+    dme_stats_dense_weighted_i32 / dme_suffix_scan_weighted.
 
-    def __init__(self, K, device=None):
+    C > 1 keeps C histograms filled from ONE pass over the rows, each row carrying C weights
+    (dme_stats_dense_weighted_batch_i32): the C component statistics of one E-step of the mixture
+    EM (CPT/dirichletMixtureEstimation.py:128-133), which the reference builds with C appendRow
+    calls per row."""
+
+    def __init__(self, K, device=None, C=1):
         self.device = require_gpu(device)
         self.K = int(K)
+        self.C = int(C)
+        if not 1 <= self.C <= 64:
+            raise ValueError("C must be in 1..64")
         self.nbins, self.tbins = 2, 2
         self._alloc()
 
     def _alloc(self):
         d = self.device
-        self.histW = torch.zeros(self.K * self.nbins, dtype=torch.float64, device=d)
-        self.histVW = torch.zeros(self.tbins, dtype=torch.float64, device=d)
+        self.histW = torch.zeros(self.C * self.K * self.nbins, dtype=torch.float64, device=d)
+        self.histVW = torch.zeros(self.C * self.tbins, dtype=torch.float64, device=d)
         self.maxcol = torch.zeros(self.K, dtype=torch.int64, device=d)
         self.maxtot = torch.zeros(1, dtype=torch.int64, device=d)
         self.status = torch.zeros(8, dtype=torch.int64, device=d)
@@ -538,26 +546,30 @@ class WeightedStats:
     def reserve(self, max_count, max_total):
         nb, tb = max(self.nbins, int(max_count) + 1), max(self.tbins, int(max_total) + 1)
         if nb != self.nbins:
-            new = torch.zeros(self.K, nb, dtype=torch.float64, device=self.device)
-            new[:, :self.nbins] = self.histW.view(self.K, self.nbins)
+            new = torch.zeros(self.C * self.K, nb, dtype=torch.float64, device=self.device)
+            new[:, :self.nbins] = self.histW.view(self.C * self.K, self.nbins)
             self.histW, self.nbins = new.view(-1), nb
         if tb != self.tbins:
-            new = torch.zeros(tb, dtype=torch.float64, device=self.device)
-            new[:self.tbins] = self.histVW
-            self.histVW, self.tbins = new, tb
+            new = torch.zeros(self.C, tb, dtype=torch.float64, device=self.device)
+            new[:, :self.tbins] = self.histVW.view(self.C, self.tbins)
+            self.histVW, self.tbins = new.view(-1), tb
 
     def add_dense(self, X, weights, max_count, max_total):
-        """X: int32 device tensor N x K (contiguous rows); weights: float64 device tensor [N]."""
+        """X: int32 device tensor N x K (contiguous rows); weights: float64 device tensor [N]
+        (C == 1) or [N, C]."""
         if X.dtype != torch.int32 or X.dim() != 2 or X.shape[1] != self.K or X.stride(1) != 1:
             raise ValueError("weighted rows must be an int32 N x K device tensor")
-        if weights.dtype != torch.float64 or weights.numel() != X.shape[0]:
-            raise ValueError("weights must be float64, one per row")
+        if weights.dtype != torch.float64 or weights.numel() != X.shape[0] * self.C:
+            raise ValueError("weights must be float64, %d per row" % self.C)
+        if weights.device != self.device or X.device != self.device:
+            raise ValueError(f"rows and weights must be on {self.device}")
+        weights = weights.contiguous()
         self.reserve(max_count, max_total)
         with _on(self.device):
-            _lib.check(_lib.lib().dme_stats_dense_weighted_i32(
-                X.data_ptr(), _ptr(weights), X.shape[0], self.K, X.stride(0), _ptr(self.histW),
-                self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol), _ptr(self.maxtot),
-                _ptr(self.status), _stream()))
+            _lib.check(_lib.lib().dme_stats_dense_weighted_batch_i32(
+                X.data_ptr(), _ptr(weights), self.C, X.shape[0], self.K, X.stride(0),
+                _ptr(self.histW), self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol),
+                _ptr(self.maxtot), _ptr(self.status), _stream()))
 
     def check(self):
         st = self.status.cpu().numpy()
@@ -566,17 +578,30 @@ class WeightedStats:
         if st[1] or st[2]:
             raise ValueError("weighted statistics incomplete: bounds passed to add_dense too small")
 
-    def add_into(self, uv):
-        """Adds the weighted suffix sums into a DeviceUV (whose U/V stop being integers)."""
+    def add_into(self, uv, c=0):
+        """Adds the weighted suffix sums of weight column c into a DeviceUV (whose U/V stop being
+        integers)."""
+        if not 0 <= c < self.C:
+            raise IndexError("weight column out of range")
         if uv.ldU < self.nbins - 1 or uv.capV < self.tbins - 1:
             raise ValueError("DeviceUV too small for the weighted statistics")
         with _on(self.device):
             _lib.check(_lib.lib().dme_suffix_scan_weighted(
-                _ptr(self.histW), self.K, self.nbins, _ptr(self.histVW), self.tbins,
+                self.histW.data_ptr() + 8 * c * self.K * self.nbins, self.K, self.nbins,
+                self.histVW.data_ptr() + 8 * c * self.tbins, self.tbins,
                 _ptr(self.maxcol), _ptr(self.maxtot), _ptr(uv.Uf), uv.ldU, _ptr(uv.lenU),
                 _ptr(uv.Vf), uv.capV, _ptr(uv.lenV), _stream()))
         uv.Ui = uv.Vi = None  # no longer exact integers
         return uv
+
+    def to_uv(self, c=0):
+        """The statistics of weight column c alone as a DeviceUV (fp64 U/V)."""
+        ldU, capV = max(self.nbins - 1, 1), max(self.tbins - 1, 1)
+        with _on(self.device):
+            buf = torch.zeros(self.K * ldU + capV, dtype=torch.float64, device=self.device)
+            lens = torch.zeros(self.K + 1, dtype=torch.int64, device=self.device)
+        uv = DeviceUV(self.K, buf[:self.K * ldU], ldU, lens[:self.K], buf[self.K * ldU:], lens[self.K:])
+        return self.add_into(uv, c)
 
 
 def predicted_step(hconst, hdiag, grad, alphas=None, device=None):

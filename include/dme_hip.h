@@ -124,6 +124,17 @@ int dme_stats_dense_weighted_i32(const int32_t* X /*[dev]*/, const double* weigh
                                  int64_t nbins, double* histVW /*[dev]*/, int64_t tbins,
                                  int64_t* maxcol /*[dev][K]*/, int64_t* maxtot /*[dev][1]*/,
                                  uint64_t* status /*[dev]*/, void* stream);
+/* The same pass with C weights per row (weights[i*C + c]): C histograms from one read of X -
+ * the C components of the mixture EM, each of which the reference feeds row by row
+ * (ConjugatePriorTools/dirichletMixtureEstimation.py:130-133 `componentCompressedData[c].appendRow(
+ * row, cProbs[c])`).  histW is [C][K][nbins], histVW [C][tbins]; maxcol / maxtot / status are
+ * shared (they do not depend on the weights).  1 <= C <= 64. */
+int dme_stats_dense_weighted_batch_i32(const int32_t* X /*[dev]*/,
+                                       const double* weights /*[dev][N][C]*/, int64_t C, int64_t N,
+                                       int64_t K, int64_t ld, double* histW /*[dev]*/,
+                                       int64_t nbins, double* histVW /*[dev]*/, int64_t tbins,
+                                       int64_t* maxcol /*[dev][K]*/, int64_t* maxtot /*[dev][1]*/,
+                                       uint64_t* status /*[dev]*/, void* stream);
 int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t nbins, const double* histVW,
                              int64_t tbins, const int64_t* maxcol, const int64_t* maxtot,
                              double* Uf /*[dev]*/, int64_t ldU, int64_t* lenU /*[dev]*/,

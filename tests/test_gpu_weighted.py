@@ -1,0 +1,91 @@
+"""Weighted rows on the device (appendRow(row, w), DE/dme.py:113-123 with w != 1; the mixture EM of
+CPT/dirichletMixtureEstimation.py:128-133 feeds C of them per row) against the oracle's literal
+loops: U/V to 1e-12 relative (fp64 sums in another order), lengths exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _rows(rng, N, K, vmax, density):
+    X = rng.integers(1, vmax + 1, size=(N, K)) * (rng.random((N, K)) < density)
+    return X.astype(np.int32)
+
+
+def _compare(uv, ref):
+    U, V = uv.to_lists()
+    assert [len(u) for u in U] == [len(u) for u in ref.U]
+    assert len(V) == len(ref.V)
+    for got, want in zip(U, ref.U):
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(V, ref.V, rtol=1e-12, atol=1e-300)
+
+
+# K = 40: every count below the LDS bin limit; K = 1000 with counts to 90: most counts above it
+# (global path) and row totals beyond the LDS total bins; K = 20000: column maxima kept in global
+# memory, no LDS count bins at all
+@pytest.mark.parametrize("N,K,vmax,density", [(3000, 40, 30, 0.6), (700, 1000, 90, 0.3),
+                                              (64, 20000, 5, 0.01), (1, 7, 3, 1.0)])
+def test_weighted_rows_vs_oracle(oracle, N, K, vmax, density):
+    from bayespy_amd import device
+    rng = np.random.default_rng(N + K)
+    X = _rows(rng, N, K, vmax, density)
+    w = rng.random(N) * 10.0 ** rng.integers(-3, 3, size=N)
+    w[::7] = 0.0   # a zero weight still lengthens U[k] (DE/dme.py:118)
+    ws = device.WeightedStats(K)
+    ws.add_dense(torch.from_numpy(X).cuda(), torch.from_numpy(w).cuda(),
+                 int(X.max()), int(X.sum(axis=1).max()))
+    ws.check()
+    _compare(ws.to_uv(), oracle.append_rows_weighted(X, w))
+
+
+def test_weighted_batch_equals_one_pass_per_weight_column(oracle):
+    """C weight columns in one pass = C separate passes (and the oracle's loops), chunked input."""
+    from bayespy_amd import device
+    rng = np.random.default_rng(5)
+    N, K, C = 5000, 96, 5
+    X = _rows(rng, N, K, 60, 0.4)
+    R = rng.dirichlet(np.ones(C), size=N)  # responsibilities: rows sum to 1
+    ws = device.WeightedStats(K, C=C)
+    mc, mt = int(X.max()), int(X.sum(axis=1).max())
+    Xd, Rd = torch.from_numpy(X).cuda(), torch.from_numpy(R).cuda()
+    for lo in range(0, N, 1800):
+        ws.add_dense(Xd[lo:lo + 1800], Rd[lo:lo + 1800], mc, mt)
+    ws.check()
+    assert int(ws.status[0]) == N
+    for c in range(C):
+        _compare(ws.to_uv(c), oracle.append_rows_weighted(X, R[:, c]))
+    # the weights of a row sum to 1: the C statistics add up to the unweighted ones
+    st = device.DeviceStats(K)
+    st.add_dense(Xd)
+    Uint, Vint = st.finalize().to_lists()
+    total = ws.to_uv(0)
+    for c in range(1, C):
+        ws.add_into(total, c)
+    Usum, Vsum = total.to_lists()
+    for got, want in zip(Usum, Uint):
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+    np.testing.assert_allclose(Vsum, Vint, rtol=1e-12)
+
+
+def test_weighted_bounds_and_negatives_are_reported():
+    from bayespy_amd import device
+    X = torch.tensor([[1, 2, 3], [4, 0, 9]], dtype=torch.int32, device="cuda")
+    w = torch.tensor([0.5, 0.25], dtype=torch.float64, device="cuda")
+    ws = device.WeightedStats(3)
+    ws.add_dense(X, w, 4, 13)  # the 9 does not fit
+    with pytest.raises(ValueError):
+        ws.check()
+    ws = device.WeightedStats(3)
+    ws.add_dense(X, w, 9, 10)  # the total 13 does not fit
+    with pytest.raises(ValueError):
+        ws.check()
+    X[0, 1] = -2
+    ws = device.WeightedStats(3)
+    ws.add_dense(X, w, 9, 13)
+    with pytest.raises(ValueError):
+        ws.check()
+    with pytest.raises(ValueError):
+        device.WeightedStats(3, C=2).add_dense(X, w, 9, 13)  # one weight per row, two expected
