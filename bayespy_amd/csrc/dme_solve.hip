@@ -545,9 +545,10 @@ __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
 __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* alpha, long long K,
                                                            long long phase, const long long* lenU,
                                                            const long long* lenV, long long ldU,
-                                                           long long capV) {
+                                                           long long capV, long long* result) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x;
+    if (result && tid < 8) result[tid] = 0;  // [6] is the done word the host polls
     build_segments(w.ctrl, lenU, lenV, K, ldU, capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
     if (tid == 0) {
         Ctrl* c = w.ctrl;
@@ -881,7 +882,7 @@ int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, alpha, (long long)K,
                        (long long)PH_EVALONLY, (const long long*)lenU, (const long long*)lenV,
-                       (long long)ldU, (long long)capV);
+                       (long long)ldU, (long long)capV, (long long*)nullptr);
     // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
     hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
                        w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
@@ -952,10 +953,9 @@ int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double*
     DME_REQUIRE(alpha && result, "null pointer");
     DME_REQUIRE(iterations >= 0 && trace_cap >= 0, "negative iterations / trace_cap");
     hipStream_t s = (hipStream_t)stream;
-    DME_HIP_CHECK(hipMemsetAsync(result, 0, 8 * sizeof(int64_t), s));
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)alpha,
                        (long long)K, (long long)PH_INIT, (const long long*)lenU,
-                       (const long long*)lenV, (long long)ldU, (long long)capV);
+                       (const long long*)lenV, (long long)ldU, (long long)capV, (long long*)result);
     DME_HIP_CHECK(hipGetLastError());
     const unsigned grid = eval_grid(w.nseg_max);
     // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)

@@ -19,7 +19,8 @@
 //     zero cells hit no real bin: a whole zero dword is skipped, a zero half of a non-zero dword is
 //     added to a sink row that is never flushed, so the hot loop has no per-element branch;
 //   * counts > B (rare) and row totals >= TB go straight to 64-bit global atomics;
-//   * at the end the workgroup flushes its non-zero LDS counters with 64-bit global atomics.
+//   * at the end the workgroup dumps its LDS histogram image as it stands (coalesced 16-byte
+//     stores); hist_reduce_kernel adds the images of all workgroups into hist / histV.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -695,9 +696,15 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
 template <typename T, int E, int J, bool MULTI, bool PACK = false>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
     auto kern = stats_dense_kernel<T, E, J, MULTI, PACK>;
-    // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB)
-    DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kLdsBudgetBytes + 1024));
+    // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
+    static bool attr_set[64] = {};
+    int dev = 0;
+    DME_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kLdsBudgetBytes + 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(p.block), p.lds_bytes, s, a);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;

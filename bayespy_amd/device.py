@@ -287,13 +287,12 @@ class DeviceStats:
             X = X.contiguous()
         if X.dtype == torch.uint16:
             fn = _lib.lib().dme_stats_dense_u16
-            as_signed = X.view(torch.int16)
         elif X.dtype == torch.int32:
             fn = _lib.lib().dme_stats_dense_i32
-            as_signed = X
         else:
             raise TypeError(f"unsupported dtype {X.dtype}: use uint16 or int32")
         if max_count is None or max_total is None:
+            as_signed = X.view(torch.int16) if X.dtype == torch.uint16 else X
             # bounds are measured, not guessed (an extra read of X, in row blocks so that the
             # widened copy stays small; avoid it by passing the bounds)
             mc, mt = 0, 0
@@ -399,15 +398,16 @@ class DeviceStats:
         if getattr(self, "_pinned", None) is None:
             self._pinned = torch.empty(8, dtype=torch.int64, pin_memory=True)
         self._pinned.copy_(self.status, non_blocking=True)
-        self._pending = torch.cuda.Event()
-        self._pending.record()
+        # no event: recording one costs ~6 us of device time on the stream; check() synchronises
+        # the stream instead, which returns at once when dme_solve has already done so
+        self._pending = torch.cuda.current_stream()
 
     def check(self):
         """Raises if the pass met data it could not count (bounds exceeded, negative cells);
         returns rows processed and the maxima seen.  Synchronises unless check_async() ran."""
         ev = getattr(self, "_pending", None)
         if ev is not None:
-            ev.synchronize()  # already complete when the stream was synchronised after it
+            ev.synchronize()  # the stream of the copy: idle already when dme_solve ran after it
             self._pending = None
             st = self._pinned.numpy().copy()
         else:
