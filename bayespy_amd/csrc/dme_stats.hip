@@ -49,7 +49,7 @@ struct StatsArgs {
     int TBpad;  // TB rounded up to a multiple of 4 words
     int WT;     // LDS table of row weights 1/(1+n) for n in [0, WT), 2 words each, at word TBpad
     int hoff;   // word offset of the count histogram in LDS = TBpad + 2*WT
-    int debug;  // unused (ablation is compile-time: DME_ABLATE below)
+    int steps;  // > 0: interleaved row mapping, loop steps per workgroup; 0: one contiguous slab each
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -182,10 +182,23 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     if (tid < 8) sh_stat[tid] = 0;
     const u32 Bpk = (u32)a.B | ((u32)a.B << 16);
 
-    const long long row0 = (long long)blockIdx.x * a.rows_per_wg;
-    const long long row1 = min(a.N, row0 + (long long)a.rows_per_wg);
+    // Row mapping.  Interleaved (a.steps > 0): in loop step t workgroup b takes the S row groups
+    // (t * gridDim.x + b) * S ..., so at any moment the whole chip reads one window of
+    // gridDim.x * S * R rows (16 MB at K = 1000) instead of gridDim.x slabs spread over the whole
+    // matrix: the window covers a handful of pages, and the kernel's time no longer depends on
+    // where the allocation happens to lie (3.32 - 3.57 ms on the same data in different buffers
+    // with one slab per workgroup).  Contiguous (a.steps == 0): workgroup b owns rows_per_wg rows.
+    constexpr long long S = (long long)W * RB;  // row groups a workgroup retires per loop step
+    // (the packed int32 kernel sits at its 128-register limit and measured 1-2 % slower with the
+    // extra index arithmetic: it keeps the slabs)
+    const bool inter = !PACK && a.steps > 0;
+    const long long row0 = inter ? 0 : (long long)blockIdx.x * a.rows_per_wg;
+    const long long row1 = inter ? a.N : min(a.N, row0 + (long long)a.rows_per_wg);
     const long long nrows = row1 > row0 ? row1 - row0 : 0;
-    const long long ngroups = (nrows + R - 1) / R;
+    const long long ngroups = inter ? (long long)a.steps * S : (nrows + R - 1) / R;
+    const long long gskip = inter ? (long long)(gridDim.x - 1) * S : 0;
+    const long long gbase = inter ? (long long)blockIdx.x * S : 0;
+    auto gmap = [&](long long g) { return g + (g / S) * gskip + gbase; };
     const u32 binRowBytes = (u32)BRW * 4u;
     // byte offset of this lane's word 0 inside a bin row; word (j, p) is (j*PW + p)*CW words on.
     const u32 laneWordByte = (u32)c * 4u;
@@ -196,14 +209,12 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     struct Buf {
         u32 d[RB][J][ND];
     };
-    const long long S = (long long)W * RB;  // row groups a workgroup retires per loop step
-
     // issue the loads of RB row groups starting at group g0 (nothing is waited for here)
     auto load_buf = [&](Buf& b, long long g0) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const long long g = g0 + (long long)rb * W;
-            const long long rowi = row0 + g * R + r;
+            const long long rowi = row0 + gmap(g) * R + r;
             const bool ok = (g < ngroups) && lane_has_row && (rowi < row1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             double w;
             if constexpr (MULTI) {
                 // ---- row-total histogram: the first lane of every row ----------------------
-                const long long rowi = row0 + g * R + r;
+                const long long rowi = row0 + gmap(g) * R + r;
                 if (lane_has_row && rowi < row1 && c == 0 && total > 0 && !DBG(8)) {
                     if ((u64)total < (u64)TB) {
                         atomicAdd(&ldsV[(u32)total], 1u);
@@ -518,7 +529,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
 
     // ---- status ------------------------------------------------------------------------------
     // (the barriers of the accumulator exchange above order the LDS counters before these reads)
-    if (tid == 0) atomicAdd(&a.status[0], (u64)nrows);
+    if (tid == 0) atomicAdd(&a.status[0], inter ? (blockIdx.x == 0 ? (u64)a.N : 0ULL) : (u64)nrows);
     if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
 }
@@ -614,9 +625,10 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
 
 constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
 constexpr int kMaxJ = 8;
+constexpr long long kRowsPerWgMax = 60000;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg;
+    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -678,8 +690,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.lds_bytes = (int)((lds + 15) & ~15LL);
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
-    // one workgroup per CU per round; a workgroup handles at most 65535 rows (16-bit LDS counters)
-    long long rounds = (N + (long long)cus * 65535 - 1) / ((long long)cus * 65535);
+    // one workgroup per CU per round; a workgroup handles at most 65535 rows (16-bit LDS counters):
+    // 60000 leaves room for the rounding of the interleaved mapping (whole loop steps)
+    long long rounds = (N + (long long)cus * kRowsPerWgMax - 1) / ((long long)cus * kRowsPerWgMax);
     if (rounds < 1) rounds = 1;
     long long grid = (long long)cus * rounds;
     long long rpw = (N + grid - 1) / grid;
@@ -689,6 +702,21 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     if (grid < 1) grid = 1;
     p.rows_per_wg = (int)rpw;
     p.grid = grid;
+    // interleaved mapping: S row groups per workgroup and loop step (S as in the kernel: waves x
+    // register-buffer depth), steps = ceil(groups / (grid * S)); a workgroup still counts at most
+    // 65535 rows
+    {
+        const int W = p.block / 64;
+        const int RB = (elem_bytes == 4 && E == 8) ? 1 : ((p.J <= 2) ? 2 : ((p.J == 4 && p.block == 512) ? 2 : 1));
+        const long long S = (long long)W * RB;
+        const long long groups = (N + p.R - 1) / p.R;
+        long long steps = (groups + grid * S - 1) / (grid * S);
+        if (steps * S * p.R > 65535) steps = 0;  // (not reached: rounds keep a margin) contiguous slabs
+        p.steps = (int)steps;
+        if (pack) p.steps = 0;
+        if (getenv("DME_STATS_CONTIGUOUS")) p.steps = 0;  // timing experiments: one slab per workgroup
+        if (p.steps == 0) p.grid = (N + rpw - 1) / rpw;
+    }
     *pl = p;
     return DME_OK;
 }
@@ -735,18 +763,6 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     Plan p;
     int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, &p);
     if (rc) return rc;
-#ifdef DME_DEBUG_HOOKS
-    if (const char* e = getenv("DME_STATS_GRIDMUL")) {
-        long long m = atoi(e);
-        if (m > 0) {
-            long long grid = p.grid * m;
-            long long rpw = (N + grid - 1) / grid;
-            if (rpw < 64) rpw = 64;
-            p.grid = (N + rpw - 1) / rpw;
-            p.rows_per_wg = (int)rpw;
-        }
-    }
-#endif
     const long long init_bytes = (p.grid * K * 8 + 255) & ~255LL;
     const long long need = init_bytes + p.grid * p.part_words * 4;
     if (!workspace || workspace_bytes < need)
@@ -755,7 +771,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, 0};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, p.steps};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if constexpr (sizeof(T) == 4) {
@@ -797,7 +813,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
 extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
-    long long rounds = (N + (long long)cus * 65535 - 1) / ((long long)cus * 65535);
+    long long rounds = (N + (long long)cus * kRowsPerWgMax - 1) / ((long long)cus * kRowsPerWgMax);
     if (rounds < 1) rounds = 1;
     // per workgroup: K fp64 mean accumulators + one raw LDS histogram image
     return (int64_t)((long long)cus * rounds * (K * 8 + kLdsBudgetBytes + 64) + 1024);
