@@ -426,3 +426,30 @@ def test_csr_partitioned_fuzz_vs_oracle(oracle, seed):
     ref = oracle.append_rows_csr(rowptr, col, val, K)
     _assert_uv_equal(st.finalize(), ref)
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize("K,N,max_total", [(512, 16_000_000, 300), (8, 40_000_000, 40)])
+def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
+    """Beyond 256 x 60000 rows the grid grows to several workgroups per CU (a workgroup's 16-bit LDS
+    counters hold 65535 rows): the interleaved row mapping must still cover every row once - row
+    count, column sums, grand total and the row-total histogram against torch reductions; K = 8 is
+    the side-by-side layout (64 rows per wave)."""
+    dev = _dev()
+    rng = np.random.default_rng(K)
+    alpha = 0.05 + rng.gamma(2.0, 0.3, size=K)
+    totals = torch.randint(1, max_total + 1, (N,), dtype=torch.int32, device="cuda",
+                           generator=torch.Generator(device="cuda").manual_seed(K))
+    X = dev.synth_dirmult(N, K, alpha, totals, seed=77)
+    st = dev.DeviceStats(K)
+    st.add_dense(X, max_count=max_total, max_total=max_total)
+    assert st.check()["rows"] == N
+    uv = st.finalize()
+    U = uv.Ui.view(K, uv.ldU)
+    colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
+    step = max(1, (256 << 20) // K)
+    for lo in range(0, N, step):
+        colsum += X[lo:lo + step].view(torch.int16).to(torch.int64).bitwise_and(0xFFFF).sum(dim=0)
+    assert torch.equal(U.sum(dim=1), colsum)
+    assert torch.equal(st.histV[:max_total + 1],
+                       torch.bincount(totals.to(torch.int64), minlength=max_total + 1))
+    assert int(uv.Vi[0]) == N
