@@ -50,6 +50,7 @@ struct StatsArgs {
     int WT;     // LDS table of row weights 1/(1+n) for n in [0, WT), 2 words each, at word TBpad
     int hoff;   // word offset of the count histogram in LDS = TBpad + 2*WT
     int steps;  // > 0: interleaved row mapping, loop steps per workgroup; 0: one contiguous slab each
+    int adjacent;  // a wave's RB rows of a loop step are adjacent rows (see the kernel)
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -182,23 +183,37 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     if (tid < 8) sh_stat[tid] = 0;
     const u32 Bpk = (u32)a.B | ((u32)a.B << 16);
 
-    // Row mapping.  Interleaved (a.steps > 0): in loop step t workgroup b takes the S row groups
-    // (t * gridDim.x + b) * S ..., so at any moment the whole chip reads one window of
-    // gridDim.x * S * R rows (16 MB at K = 1000) instead of gridDim.x slabs spread over the whole
-    // matrix: the window covers a handful of pages, and the kernel's time no longer depends on
-    // where the allocation happens to lie (3.32 - 3.57 ms on the same data in different buffers
-    // with one slab per workgroup).  Contiguous (a.steps == 0): workgroup b owns rows_per_wg rows.
+    // Row mapping.  A loop step retires a tile of S = W * RB adjacent row groups; a wave takes RB
+    // of them.
+    //  * Interleaved tiles (a.steps > 0): workgroup b takes tiles b, b + gridDim.x, ..., so at any
+    //    moment the whole chip reads one window of gridDim.x tiles (16 MB at K = 1000) that moves
+    //    through the matrix, instead of gridDim.x slabs spread over all of it: the window covers a
+    //    handful of pages and the kernel's time no longer depends on where the allocation happens
+    //    to lie (3.32 - 3.57 ms on the same data in different buffers with one slab per
+    //    workgroup).  Contiguous (a.steps == 0): workgroup b owns the rows_per_wg rows of slab b.
+    //  * Within a tile wave w takes rows w, w + W, ... (a.adjacent == 0) or the RB adjacent rows
+    //    w * RB ... (a.adjacent != 0).  When the row pitch is not a multiple of the 128-byte cache
+    //    line, neighbouring rows share a line and the non-temporal stream fetches it once per
+    //    load instruction that touches it, unless the two loads come from one wave back to back:
+    //    adjacent rows in one wave halve those double fetches (K = 1000: 3.32 -> 3.25 ms).  With
+    //    line-aligned rows there is nothing to save and the strided order measured 1-4 % faster
+    //    (profiles/r1_notes.md).
     constexpr long long S = (long long)W * RB;  // row groups a workgroup retires per loop step
-    // (the packed int32 kernel sits at its 128-register limit and measured 1-2 % slower with the
-    // extra index arithmetic: it keeps the slabs)
+    // (the packed int32 kernel sits at its 128-register limit and measured 1-2 % slower
+    // interleaved: it keeps the slabs)
     const bool inter = !PACK && a.steps > 0;
+    const bool adjacent = a.adjacent != 0;
     const long long row0 = inter ? 0 : (long long)blockIdx.x * a.rows_per_wg;
     const long long row1 = inter ? a.N : min(a.N, row0 + (long long)a.rows_per_wg);
     const long long nrows = row1 > row0 ? row1 - row0 : 0;
-    const long long ngroups = inter ? (long long)a.steps * S : (nrows + R - 1) / R;
-    const long long gskip = inter ? (long long)(gridDim.x - 1) * S : 0;
-    const long long gbase = inter ? (long long)blockIdx.x * S : 0;
-    auto gmap = [&](long long g) { return g + (g / S) * gskip + gbase; };
+    // loop steps of this workgroup (rows beyond row1 load as zeros), row groups between its tiles,
+    // its first tile, and the place of this wave's rb-th row group inside a tile
+    const long long nsteps = inter ? (long long)a.steps : ((nrows + R - 1) / R + S - 1) / S;
+    const long long tile_pitch = inter ? (long long)gridDim.x * S : S;
+    const long long tile0 = inter ? (long long)blockIdx.x * S : 0;
+    int goff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) goff[rb] = adjacent ? wave * RB + rb : rb * W + wave;
     const u32 binRowBytes = (u32)BRW * 4u;
     // byte offset of this lane's word 0 inside a bin row; word (j, p) is (j*PW + p)*CW words on.
     const u32 laneWordByte = (u32)c * 4u;
@@ -209,13 +224,13 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     struct Buf {
         u32 d[RB][J][ND];
     };
-    // issue the loads of RB row groups starting at group g0 (nothing is waited for here)
-    auto load_buf = [&](Buf& b, long long g0) {
+    // issue the loads of this wave's RB row groups of the tile at row group `tile` (nothing is
+    // waited for here; a tile beyond the last one holds no rows below row1)
+    auto load_buf = [&](Buf& b, long long tile) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const long long g = g0 + (long long)rb * W;
-            const long long rowi = row0 + gmap(g) * R + r;
-            const bool ok = (g < ngroups) && lane_has_row && (rowi < row1);
+            const long long rowi = row0 + (tile + goff[rb]) * R + r;
+            const bool ok = lane_has_row && (rowi < row1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int chunk = c + 64 * j;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
         }
     };
 
-    auto process_buf = [&](Buf& b, long long g0) {
+    auto process_buf = [&](Buf& b, long long tile) {
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
 #pragma unroll
@@ -304,13 +319,13 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const long long g = g0 + (long long)rb * W;
-            if (g >= ngroups) break;  // wave-uniform
+            const long long pg = tile + goff[rb];
+            if (row0 + pg * R >= row1) continue;  // wave-uniform: no such rows
             const SumT total = tot[rb];
             double w;
             if constexpr (MULTI) {
                 // ---- row-total histogram: the first lane of every row ----------------------
-                const long long rowi = row0 + gmap(g) * R + r;
+                const long long rowi = row0 + pg * R + r;
                 if (lane_has_row && rowi < row1 && c == 0 && total > 0 && !DBG(8)) {
                     if ((u64)total < (u64)TB) {
                         atomicAdd(&ldsV[(u32)total], 1u);
@@ -478,19 +493,20 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     // Software pipeline, two register buffers: the loads of the next RB row groups are in flight
     // while the current ones are processed (the compiler places counted s_waitcnt vmcnt).
     {
-        long long g = wave;
-        if (g < ngroups) {
+        if (nsteps > 0) {
             Buf bufA, bufB;
-            load_buf(bufA, g);
+            long long tile = tile0;
+            long long k = 0;
+            load_buf(bufA, tile);
             while (true) {
-                load_buf(bufB, g + S);
-                process_buf(bufA, g);
-                g += S;
-                if (g >= ngroups) break;
-                load_buf(bufA, g + S);
-                process_buf(bufB, g);
-                g += S;
-                if (g >= ngroups) break;
+                load_buf(bufB, tile + tile_pitch);
+                process_buf(bufA, tile);
+                tile += tile_pitch;
+                if (++k >= nsteps) break;
+                load_buf(bufA, tile + tile_pitch);
+                process_buf(bufB, tile);
+                tile += tile_pitch;
+                if (++k >= nsteps) break;
             }
         }
     }
@@ -628,7 +644,7 @@ constexpr int kMaxJ = 8;
 constexpr long long kRowsPerWgMax = 60000;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps;
+    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -711,9 +727,11 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         const long long S = (long long)W * RB;
         const long long groups = (N + p.R - 1) / p.R;
         long long steps = (groups + grid * S - 1) / (grid * S);
-        if (steps * S * p.R > 65535) steps = 0;  // (not reached: rounds keep a margin) contiguous slabs
+        if (steps * S * p.R > 65535) steps = 0;  // contiguous slabs (rows_per_wg <= 60000 each)
         p.steps = (int)steps;
         if (pack) p.steps = 0;
+        // rows that share cache lines with their neighbours (pitch not a multiple of 128 bytes)
+        p.adjacent = (!p.multi && (ld * elem_bytes) % 128 != 0) ? 1 : 0;
         if (getenv("DME_STATS_CONTIGUOUS")) p.steps = 0;  // timing experiments: one slab per workgroup
         if (p.steps == 0) p.grid = (N + rpw - 1) / rpw;
     }
@@ -771,7 +789,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, p.steps};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, p.steps, p.adjacent};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if constexpr (sizeof(T) == 4) {
