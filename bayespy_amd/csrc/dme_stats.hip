@@ -61,6 +61,10 @@ struct StatsArgs {
 #endif
 #define DBG(bit) ((DME_ABLATE) & (bit))
 
+// row groups per register buffer of the one-vector-per-lane kernels (rows up to 1 KB)
+#ifndef DME_RB1
+#define DME_RB1 4
+#endif
 // dwords of a vector load handled under one exec mask in the uint16 cell loop (1, 2 or 4)
 #ifndef DME_GROUP
 #define DME_GROUP 1
@@ -127,7 +131,7 @@ struct StatsCfg {
     static constexpr int BLOCK = (J * E >= 64) ? 256 : ((J * E > 16) ? 512 : 1024);
     // row groups per register buffer (two buffers): enough 16-byte loads in flight per CU
     // (ES == 4 with E == 8 is the packed-int32 kernel: its raw buffers are twice the size)
-    static constexpr int RB = (ES == 4 && E == 8) ? 1 : ((J <= 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1));
+    static constexpr int RB = (ES == 4 && E == 8) ? 1 : ((J == 1) ? DME_RB1 : ((J == 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1)));
 };
 
 // T: element type (unsigned short | int).  E: elements per vector (chunk).  J: vectors per lane
@@ -723,7 +727,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // 65535 rows
     {
         const int W = p.block / 64;
-        const int RB = (elem_bytes == 4 && E == 8) ? 1 : ((p.J <= 2) ? 2 : ((p.J == 4 && p.block == 512) ? 2 : 1));
+        const int RB = (elem_bytes == 4 && E == 8) ? 1 : ((p.J == 1) ? DME_RB1 : ((p.J == 2) ? 2 : ((p.J == 4 && p.block == 512) ? 2 : 1)));
         const long long S = (long long)W * RB;
         const long long groups = (N + p.R - 1) / p.R;
         long long steps = (groups + grid * S - 1) / (grid * S);
@@ -732,6 +736,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         if (pack) p.steps = 0;
         // rows that share cache lines with their neighbours (pitch not a multiple of 128 bytes)
         p.adjacent = (!p.multi && (ld * elem_bytes) % 128 != 0) ? 1 : 0;
+        if (const char* e = getenv("DME_STATS_ADJ")) p.adjacent = atoi(e);  // timing experiments
         if (getenv("DME_STATS_CONTIGUOUS")) p.steps = 0;  // timing experiments: one slab per workgroup
         if (p.steps == 0) p.grid = (N + rpw - 1) / rpw;
     }
