@@ -27,11 +27,17 @@ EXIT_MESSAGES = {
 }
 
 
+_GPU_CHECKED = False
+
+
 def require_gpu(device=None):
-    if not torch.cuda.is_available():
-        raise RuntimeError("bayespy_amd needs an AMD GPU (MI355X, ROCm): no HIP device is visible "
-                           "and there is no CPU fallback")
-    _lib.lib()
+    global _GPU_CHECKED
+    if not _GPU_CHECKED:  # once: the answer does not change within a process
+        if not torch.cuda.is_available():
+            raise RuntimeError("bayespy_amd needs an AMD GPU (MI355X, ROCm): no HIP device is "
+                               "visible and there is no CPU fallback")
+        _lib.lib()
+        _GPU_CHECKED = True
     if device is None:
         return torch.device("cuda", torch.cuda.current_device())
     device = torch.device(device)
@@ -50,7 +56,14 @@ def _on(device):
     return _SAME_DEVICE if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current stream of the current device as a raw hipStream_t (called before every launch:
+    the direct binding costs a fraction of a microsecond, torch.cuda.current_stream() several)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
