@@ -46,9 +46,13 @@ struct StatsArgs {
     int B;    // LDS-privatised count bins 1..B (row 0 of the LDS histogram is the sink)
     int BRW;  // 32-bit words per LDS bin row
     int TB;   // LDS-privatised row-total bins [0, TB)
-    int TBpad;  // TB rounded up to a multiple of 4 words
-    int WT;     // LDS table of row weights 1/(1+n) for n in [0, WT), 2 words each, at word TBpad
-    int hoff;   // word offset of the count histogram in LDS = TBpad + 2*WT
+    int TBpad;  // words from one copy of the row-total bins to the next (>= TB; odd when VC > 1, so
+                // that equal totals of different row slots fall into different LDS banks)
+    int VC;     // copies of the row-total bins (side-by-side rows: a wave's 64 / C rows add at once)
+    int Vw;     // words of all copies together, a multiple of 4
+    int WT;     // LDS table of row weights 1/(1+n) for n in [0, WT), 2 words each, at word Vw
+    int hoff;   // word offset of the count histogram in LDS = Vw + 2*WT
+    int CW;     // side-by-side rows: LDS words per (j, p) group of a bin row (C, or 64 = one per lane)
     int steps;  // > 0: interleaved row mapping, loop steps per workgroup; 0: one contiguous slab each
     int adjacent;  // a wave's RB rows of a loop step are adjacent rows (see the kernel)
 };
@@ -161,18 +165,20 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     const int r = MULTI ? lane / C : 0;
     const int c = MULTI ? lane - r * C : lane;
     const bool lane_has_row = MULTI ? (r < R) : true;
-    const int CW = MULTI ? C : 64;
+    const int CC = MULTI ? C : 64;  // column chunks a wave covers per vector index j
+    const int CW = MULTI ? a.CW : 64;  // LDS words per (j, p) group of a bin row: C, or one per lane
     const int B = a.B, BRW = a.BRW, TB = a.TB;
     u32* ldsV = lds;
     u32* ldsH = lds + a.hoff;
-    const double* ldsW = (const double*)(lds + a.TBpad);
+    const double* ldsW = (const double*)(lds + a.Vw);
     const int WT = a.WT;
+    const u32 vcopy = MULTI ? (u32)((r & (a.VC - 1)) * a.TBpad) : 0u;  // this row slot's copy of the bins
     const int nwords = (int)a.part_words;  // TB + (B+1)*BRW rounded up to a multiple of 4
     for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
     __syncthreads();
     // weightForMean = 1.0 / (1.0 + sumData) (DE/fdp.py:88), tabulated once per workgroup
     for (int n = tid; n < WT; n += BLOCK)
-        ((double*)(lds + a.TBpad))[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
+        ((double*)(lds + a.Vw))[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
     __syncthreads();
 
     double acc[J][E];
@@ -220,7 +226,12 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     for (int rb = 0; rb < RB; ++rb) goff[rb] = adjacent ? wave * RB + rb : rb * W + wave;
     const u32 binRowBytes = (u32)BRW * 4u;
     // byte offset of this lane's word 0 inside a bin row; word (j, p) is (j*PW + p)*CW words on.
-    const u32 laneWordByte = (u32)c * 4u;
+    // Many side-by-side rows (a.CW == 64: 16 or more per wave) keep a word per LANE, not per column
+    // chunk: the wave's rows would otherwise add equal counts of one column to one word, and
+    // same-address LDS atomics serialise (K = 16: 1.25 -> 0.89 ms for 4 GB; hist_reduce_kernel adds
+    // the row slots' words of a column together).  With few rows per wave the narrower layout
+    // measured 1 % faster.
+    const u32 laneWordByte = (u32)((MULTI && CW == 64) ? lane : c) * 4u;
     char* ldsHb = (char*)ldsH;
     const T* Xp = (const T*)a.X;
     const long long nbins = a.nbins, tbins = a.tbins;
@@ -332,7 +343,10 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                 const long long rowi = row0 + pg * R + r;
                 if (lane_has_row && rowi < row1 && c == 0 && total > 0 && !DBG(8)) {
                     if ((u64)total < (u64)TB) {
-                        atomicAdd(&ldsV[(u32)total], 1u);
+                        // Rows of similar totals (coin-flip data: one fixed number of trials) would
+                        // send the wave's adds to a few LDS words, which serialises them: the
+                        // row slots of a wave are spread over VC copies of the bins.
+                        atomicAdd(&ldsV[vcopy + (u32)total], 1u);
                     } else {
                         atomicMax(&sh_stat[5], (u64)total);
                         if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
@@ -534,7 +548,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
 #pragma unroll
         for (int e = 0; e < E; ++e) ldsD[tid * E + e] = acc[j][e];
         __syncthreads();
-        for (int t = tid; t < CW * E; t += BLOCK) {
+        for (int t = tid; t < CC * E; t += BLOCK) {
             const int cc = t / E, e = t - cc * E;
             const int chunk = MULTI ? cc : cc + 64 * j;
             if (chunk < C) {
@@ -588,14 +602,15 @@ struct ReduceArgs {
     u64* histV;
     u64* status;
     long long K;
-    int C, B, BRW, TB, TBpad, hoff, CW, PW, E, multi;
+    int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi;
 };
 
 __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs a) {
     __shared__ u64 shlo[RED_SLICES][64], shhi[RED_SLICES][64];
     const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;  // word index in the image
     const long long used = a.hoff + (long long)(a.B + 1) * a.BRW;
-    const bool isV = idx < a.TB;
+    const long long vt = idx % a.TBpad;  // the bin, if idx lies in one of the VC copies of the row-total bins
+    const bool isV = idx < (long long)a.VC * a.TBpad && vt < a.TB;
     const bool isH = idx >= a.hoff + a.BRW && idx < used;  // skips the weight table and the sink row
     u64 lo = 0, hi = 0;
     if (isV || isH)
@@ -618,8 +633,9 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
     if (isV) {  // row-total bins: plain 32-bit counters
         const u64 cnt = lo + (hi << 16);
         if (cnt) {
-            a.histV[idx] += cnt;
-            maxt = (u64)idx;
+            if (a.VC > 1) atomicAdd(&a.histV[vt], cnt);  // VC words per bin
+            else a.histV[vt] += cnt;
+            maxt = (u64)vt;
         }
     } else if (isH && (lo | hi)) {
         const u32 h = (u32)(idx - a.hoff);
@@ -627,11 +643,19 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
         const u32 wi = h - v * (u32)a.BRW;
         const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
         const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
-        const u32 chunk = a.multi ? cc : cc + 64u * j;
-        if (chunk < (u32)a.C) {
+        // side-by-side rows: word cc belongs to lane cc = row slot cc / C, column chunk cc % C
+        const bool lanes = a.multi && a.CW == 64 && a.C < 64;
+        const bool used = lanes ? cc < (u32)(a.R * a.C) : true;
+        const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
+        if (used && chunk < (u32)a.C) {
             const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
-            if (lo) a.hist[k0 * a.nbins + v] += lo;
-            if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
+            if (lanes && a.R > 1) {  // R words per bin
+                if (lo) atomicAdd(&a.hist[k0 * a.nbins + v], lo);
+                if (hi) atomicAdd(&a.hist[(k0 + 1) * a.nbins + v], hi);
+            } else {
+                if (lo) a.hist[k0 * a.nbins + v] += lo;
+                if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
+            }
             maxv = v;
         }
     }
@@ -648,7 +672,7 @@ constexpr int kMaxJ = 8;
 constexpr long long kRowsPerWgMax = 60000;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent;
+    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -685,14 +709,21 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         p.R = 1;
     }
     const int PW = E >= 2 ? E / 2 : 1;
-    const int CW = p.multi ? (int)C : 64;
+    const int CW = (p.multi && p.R < 16) ? (int)C : 64;  // many side-by-side rows: a word per lane (see the kernel)
+    p.CW = CW;
     p.BRW = p.J * PW * CW;
     const int JE = p.J * E;
     p.block = (JE >= 64) ? 256 : ((JE > 16) ? 512 : 1024);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
-    const long long hoff = TBpad + 2 * WT;
+    // copies of the row-total bins for side-by-side rows: one per row slot, within 4096 words
+    long long VC = 1;
+    if (p.multi)
+        while (VC < 64 && VC * 2 <= p.R && VC * 2 * (TBpad + 1) <= 4096 + 64) VC *= 2;
+    const long long Vstride = VC > 1 ? TBpad + 1 : TBpad;  // odd: spreads equal totals over the banks
+    const long long Vw = (VC * Vstride + 3) & ~3LL;
+    const long long hoff = Vw + 2 * WT;
     long long avail = kLdsBudgetBytes / 4 - hoff - 4;
     long long B = avail / p.BRW - 1;
     if (B > nbins - 1) B = nbins - 1;
@@ -700,7 +731,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     if (B < 0) B = 0;
     p.B = (int)B;
     p.TB = (int)TB;
-    p.TBpad = (int)TBpad;
+    p.TBpad = (int)Vstride;
+    p.VC = (int)VC;
+    p.Vw = (int)Vw;
     p.WT = (int)WT;
     p.hoff = (int)hoff;
     p.part_words = (hoff + (B + 1) * (long long)p.BRW + 3) & ~3LL;
@@ -794,7 +827,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.WT, p.hoff, p.steps, p.adjacent};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if constexpr (sizeof(T) == 4) {
@@ -821,7 +854,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     if (rc) return rc;
     const int PW = p.E >= 2 ? p.E / 2 : 1;
     ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
-                  p.C, p.B, p.BRW, p.TB, p.TBpad, p.hoff, p.multi ? p.C : 64, PW, p.E,
+                  p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
                   p.multi ? 1 : 0};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
     hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, RED_SLICES), 0, s, ra);
