@@ -709,7 +709,10 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         p.R = 1;
     }
     const int PW = E >= 2 ? E / 2 : 1;
-    const int CW = (p.multi && p.R < 16) ? (int)C : 64;  // many side-by-side rows: a word per lane (see the kernel)
+    // many side-by-side rows: a word per lane (see the kernel) - when there are rows enough to repay
+    // the larger images that every workgroup dumps and hist_reduce_kernel sums (~20 us)
+    const bool many_rows = N >= 4000000;
+    const int CW = (p.multi && (p.R < 16 || !many_rows)) ? (int)C : 64;
     p.CW = CW;
     p.BRW = p.J * PW * CW;
     const int JE = p.J * E;
@@ -719,7 +722,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
     // copies of the row-total bins for side-by-side rows: one per row slot, within 4096 words
     long long VC = 1;
-    if (p.multi)
+    if (p.multi && many_rows)
         while (VC < 64 && VC * 2 <= p.R && VC * 2 * (TBpad + 1) <= 4096 + 64) VC *= 2;
     const long long Vstride = VC > 1 ? TBpad + 1 : TBpad;  // odd: spreads equal totals over the banks
     const long long Vw = (VC * Vstride + 3) & ~3LL;

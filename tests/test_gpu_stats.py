@@ -428,12 +428,14 @@ def test_csr_partitioned_fuzz_vs_oracle(oracle, seed):
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
 
 
-@pytest.mark.parametrize("K,N,max_total", [(512, 16_000_000, 300), (8, 40_000_000, 40)])
+@pytest.mark.parametrize("K,N,max_total", [(512, 16_000_000, 300), (8, 40_000_000, 40),
+                                           (24, 5_000_000, 50), (2, 6_000_000, 60)])
 def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
     """Beyond 256 x 60000 rows the grid grows to several workgroups per CU (a workgroup's 16-bit LDS
     counters hold 65535 rows): the interleaved row mapping must still cover every row once - row
     count, column sums, grand total and the row-total histogram against torch reductions; K = 8 is
-    the side-by-side layout (64 rows per wave)."""
+    the side-by-side layout (64 rows per wave); K = 24 carries 21 rows per wave (a bin word per
+    lane, 16 copies of the row-total bins), K = 2 one row per lane."""
     dev = _dev()
     rng = np.random.default_rng(K)
     alpha = 0.05 + rng.gamma(2.0, 0.3, size=K)
