@@ -455,3 +455,32 @@ def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
     assert torch.equal(st.histV[:max_total + 1],
                        torch.bincount(totals.to(torch.int64), minlength=max_total + 1))
     assert int(uv.Vi[0]) == N
+
+
+@pytest.mark.parametrize("K,dtype", [(16, "u16"), (2, "i32"), (24, "u16")])
+def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype):
+    """From 4 M rows on, rows that lie 16 or more side by side in a wave use a bin word per lane and
+    a copy of the row-total bins per row slot (summed by hist_reduce_kernel): U/V bit-exact and the
+    mean accumulator to 1e-12 against the oracle's loops at that size; one row total dominates
+    (the fixed-number-of-trials case the layout is for) and a few counts exceed the LDS bins."""
+    N = 4_200_000
+    rng = np.random.default_rng(K)
+    X = rng.integers(0, 9, size=(N, K), dtype=np.int32)
+    X[::3] = 0
+    X[::3, 0] = 60                                        # a third of the rows: total exactly 60
+    X[rng.integers(0, N, 50), rng.integers(0, K, 50)] = 700   # beyond the LDS bins
+    ref = oracle.append_rows(X.astype(np.uint16) if dtype == "u16" else X)
+    st, uv, info = _build(X, dtype)
+    assert info["rows"] == N
+    _assert_uv_equal(uv, ref)
+    # the mean accumulator: the oracle adds 4.2 M terms one after the other as the reference does
+    # (rounding ~1e-11 relative at this length), the kernel in a tree; both against an extended-
+    # precision sum, the kernel at the tighter bound
+    n = X.sum(axis=1, dtype=np.int64)
+    exact = np.zeros(K, dtype=np.longdouble)
+    for lo in range(0, N, 500_000):
+        w = np.longdouble(1) / (1 + n[lo:lo + 500_000]).astype(np.longdouble)
+        exact += (X[lo:lo + 500_000].astype(np.longdouble) * w[:, None]).sum(axis=0)
+    exact = exact.astype(np.float64)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), exact, rtol=1e-13)
+    np.testing.assert_allclose(ref.init_acc, exact, rtol=1e-10)
