@@ -606,57 +606,82 @@ struct ReduceArgs {
 };
 
 __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs a) {
-    __shared__ u64 shlo[RED_SLICES][64], shhi[RED_SLICES][64];
-    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;  // word index in the image
+    // a thread column owns four consecutive image words (one 16-byte load per image); the slices'
+    // partial sums meet in LDS as (hi << 32 | lo) pairs of the two packed 16-bit counters
+    __shared__ u64 sh[RED_SLICES][64][4];
+    const long long idx4 = ((long long)blockIdx.x * 64 + threadIdx.x) * 4;  // first word index in the image
     const long long used = a.hoff + (long long)(a.B + 1) * a.BRW;
-    const long long vt = idx % a.TBpad;  // the bin, if idx lies in one of the VC copies of the row-total bins
-    const bool isV = idx < (long long)a.VC * a.TBpad && vt < a.TB;
-    const bool isH = idx >= a.hoff + a.BRW && idx < used;  // skips the weight table and the sink row
-    u64 lo = 0, hi = 0;
-    if (isV || isH)
-        for (long long g = threadIdx.y; g < a.G; g += RED_SLICES) {
-            const u32 w = a.hist_part[g * a.part_words + idx];
-            lo += w & 0xffffu;
-            hi += w >> 16;
+    u32 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+    if (idx4 < a.part_words) {  // part_words is a multiple of 4
+        const u32x4* src = (const u32x4*)(a.hist_part + idx4);
+        const long long stride4 = a.part_words >> 2;
+        long long g = threadIdx.y;
+        for (; g + 3 * RED_SLICES < a.G; g += 4 * RED_SLICES) {  // four loads in flight
+            u32x4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = src[(g + q * RED_SLICES) * stride4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                lo[0] += w[q].x & 0xffffu; hi[0] += w[q].x >> 16;
+                lo[1] += w[q].y & 0xffffu; hi[1] += w[q].y >> 16;
+                lo[2] += w[q].z & 0xffffu; hi[2] += w[q].z >> 16;
+                lo[3] += w[q].w & 0xffffu; hi[3] += w[q].w >> 16;
+            }
         }
-    shlo[threadIdx.y][threadIdx.x] = lo;
-    shhi[threadIdx.y][threadIdx.x] = hi;
+        for (; g < a.G; g += RED_SLICES) {
+            const u32x4 w = src[g * stride4];
+            lo[0] += w.x & 0xffffu; hi[0] += w.x >> 16;
+            lo[1] += w.y & 0xffffu; hi[1] += w.y >> 16;
+            lo[2] += w.z & 0xffffu; hi[2] += w.z >> 16;
+            lo[3] += w.w & 0xffffu; hi[3] += w.w >> 16;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sh[threadIdx.y][threadIdx.x][q] = (u64)lo[q] | ((u64)hi[q] << 32);
     __syncthreads();
     if (threadIdx.y != 0) return;  // one full wave goes on
-    lo = hi = 0;
-#pragma unroll
-    for (int y = 0; y < RED_SLICES; ++y) {
-        lo += shlo[y][threadIdx.x];
-        hi += shhi[y][threadIdx.x];
-    }
     u64 maxv = 0, maxt = 0;
-    if (isV) {  // row-total bins: plain 32-bit counters
-        const u64 cnt = lo + (hi << 16);
-        if (cnt) {
-            if (a.VC > 1) atomicAdd(&a.histV[vt], cnt);  // VC words per bin
-            else a.histV[vt] += cnt;
-            maxt = (u64)vt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u64 slo = 0, shi = 0;
+#pragma unroll
+        for (int y = 0; y < RED_SLICES; ++y) {
+            const u64 x = sh[y][threadIdx.x][q];
+            slo += x & 0xffffffffu;
+            shi += x >> 32;
         }
-    } else if (isH && (lo | hi)) {
-        const u32 h = (u32)(idx - a.hoff);
-        const u32 v = h / (u32)a.BRW;
-        const u32 wi = h - v * (u32)a.BRW;
-        const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
-        const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
-        // side-by-side rows: word cc belongs to lane cc = row slot cc / C, column chunk cc % C
-        const bool lanes = a.multi && a.CW == 64 && a.C < 64;
-        const bool used = lanes ? cc < (u32)(a.R * a.C) : true;
-        const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
-        if (used && chunk < (u32)a.C) {
-            const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
-            if (lanes && a.R > 1) {  // R words per bin
-                if (lo) atomicAdd(&a.hist[k0 * a.nbins + v], lo);
-                if (hi) atomicAdd(&a.hist[(k0 + 1) * a.nbins + v], hi);
-            } else {
-                if (lo) a.hist[k0 * a.nbins + v] += lo;
-                if (hi) a.hist[(k0 + 1) * a.nbins + v] += hi;
+        const long long idx = idx4 + q;
+        const long long vt = idx % a.TBpad;  // the bin, if idx lies in one of the VC copies of the row-total bins
+        const bool isV = idx < (long long)a.VC * a.TBpad && vt < a.TB;
+        const bool isH = idx >= a.hoff + a.BRW && idx < used;  // skips the weight table and the sink row
+        if (isV) {  // row-total bins: plain 32-bit counters
+            const u64 cnt = slo + (shi << 16);
+            if (cnt) {
+                if (a.VC > 1) atomicAdd(&a.histV[vt], cnt);  // VC words per bin
+                else a.histV[vt] += cnt;
+                maxt = maxt > (u64)vt ? maxt : (u64)vt;
             }
-            maxv = v;
+        } else if (isH && (slo | shi)) {
+            const u32 h = (u32)(idx - a.hoff);
+            const u32 v = h / (u32)a.BRW;
+            const u32 wi = h - v * (u32)a.BRW;
+            const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
+            const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
+            // side-by-side rows: word cc belongs to lane cc = row slot cc / C, column chunk cc % C
+            const bool lanes = a.multi && a.CW == 64 && a.C < 64;
+            const bool live = lanes ? cc < (u32)(a.R * a.C) : true;
+            const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
+            if (live && chunk < (u32)a.C) {
+                const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
+                if (lanes && a.R > 1) {  // R words per bin
+                    if (slo) atomicAdd(&a.hist[k0 * a.nbins + v], slo);
+                    if (shi) atomicAdd(&a.hist[(k0 + 1) * a.nbins + v], shi);
+                } else {
+                    if (slo) a.hist[k0 * a.nbins + v] += slo;
+                    if (shi) a.hist[(k0 + 1) * a.nbins + v] += shi;
+                }
+                maxv = maxv > (u64)v ? maxv : (u64)v;
+            }
         }
     }
     maxv = dme_wave_max_u64(maxv);
@@ -860,7 +885,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
                   p.multi ? 1 : 0};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
-    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 63) / 64)), dim3(64, RED_SLICES), 0, s, ra);
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 255) / 256)), dim3(64, RED_SLICES), 0, s, ra);
     hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, RED_SLICES), 0, s,
                        (const double*)workspace, p.grid, K, init_acc);
     DME_HIP_CHECK(hipGetLastError());
