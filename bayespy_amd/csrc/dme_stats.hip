@@ -572,11 +572,10 @@ constexpr int RED_SLICES = 16;  // interleaved slices of workgroups per output (
 
 // init_acc[k] += sum over workgroups of part[g][k], in a fixed order: RED_SLICES interleaved slices
 // of g per column, combined in slice order through LDS.
-__global__ __launch_bounds__(64 * RED_SLICES) void init_reduce_kernel(const double* part,
-                                                                      long long G, long long K,
-                                                                      double* init_acc) {
+__device__ void init_reduce_block(long long block, const double* part, long long G, long long K,
+                                  double* init_acc) {
     __shared__ double sh[RED_SLICES][64];
-    const long long k = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long k = block * 64 + threadIdx.x;
     double s = 0.0;
     if (k < K)
         for (long long g = threadIdx.y; g < G; g += RED_SLICES) s = __dadd_rn(s, part[g * K + k]);
@@ -603,11 +602,19 @@ struct ReduceArgs {
     u64* status;
     long long K;
     int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi;
+    // the mean accumulators ride in the same launch: blocks from hist_blocks on sum part[g][k]
+    long long hist_blocks;
+    const double* part;
+    double* init_acc;
 };
 
 __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs a) {
     // a thread column owns four consecutive image words (one 16-byte load per image); the slices'
     // partial sums meet in LDS as (hi << 32 | lo) pairs of the two packed 16-bit counters
+    if ((long long)blockIdx.x >= a.hist_blocks) {  // block-uniform
+        init_reduce_block((long long)blockIdx.x - a.hist_blocks, a.part, a.G, a.K, a.init_acc);
+        return;
+    }
     __shared__ u64 sh[RED_SLICES][64][4];
     const long long idx4 = ((long long)blockIdx.x * 64 + threadIdx.x) * 4;  // first word index in the image
     const long long used = a.hoff + (long long)(a.B + 1) * a.BRW;
@@ -885,9 +892,11 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
                   p.multi ? 1 : 0};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
-    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)((used + 255) / 256)), dim3(64, RED_SLICES), 0, s, ra);
-    hipLaunchKernelGGL(init_reduce_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64, RED_SLICES), 0, s,
-                       (const double*)workspace, p.grid, K, init_acc);
+    ra.hist_blocks = (used + 255) / 256;
+    ra.part = (const double*)workspace;
+    ra.init_acc = init_acc;
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)(ra.hist_blocks + (K + 63) / 64)),
+                       dim3(64, RED_SLICES), 0, s, ra);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }
