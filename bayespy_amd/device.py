@@ -286,7 +286,7 @@ class DeviceStats:
     def add_dense(self, X, max_count=None, max_total=None):
         """Adds every row of X (device tensor, uint16 or int32, row-major N x K).  max_count /
         max_total are upper bounds on a cell / a row total; when omitted they are measured with
-        one extra pass over X (torch), so pass them when known.  Asynchronous; data errors
+        one extra streaming pass over X (dme_bounds_dense_*), so pass them when known.  Asynchronous; data errors
         (bounds exceeded, negative cells) surface in check()."""
         if not isinstance(X, torch.Tensor):
             raise TypeError("X must be a torch tensor on the GPU")
@@ -305,17 +305,14 @@ class DeviceStats:
         else:
             raise TypeError(f"unsupported dtype {X.dtype}: use uint16 or int32")
         if max_count is None or max_total is None:
-            as_signed = X.view(torch.int16) if X.dtype == torch.uint16 else X
-            # bounds are measured, not guessed (an extra read of X, in row blocks so that the
-            # widened copy stays small; avoid it by passing the bounds)
-            mc, mt = 0, 0
-            step = max(1, (64 << 20) // max(self.K, 1))
-            for lo in range(0, X.shape[0], step):
-                wide = as_signed[lo:lo + step].to(torch.int64)
-                if X.dtype == torch.uint16:
-                    wide = wide & 0xFFFF
-                mc = max(mc, int(wide.max()))
-                mt = max(mt, int(wide.sum(dim=1).max()))
+            # bounds are measured, not guessed: one extra streaming read of X (dme_bounds_dense_*);
+            # avoid it by passing the bounds
+            with _on(self.device):
+                out = torch.zeros(2, dtype=torch.int64, device=self.device)
+                bfn = (_lib.lib().dme_bounds_dense_u16 if X.dtype == torch.uint16
+                       else _lib.lib().dme_bounds_dense_i32)
+                _lib.check(bfn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(out), _stream()))
+                mc, mt = (int(v) for v in out.cpu())
             max_count = mc if max_count is None else max_count
             max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)

@@ -45,6 +45,19 @@ const char* dme_last_error(void);
 int dme_device_cus(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Extents for the histograms.  The reference lengthens U[k] / V as rows arrive (DE/dme.py:118, :122);
+ * here nbins / tbins are fixed before the statistics pass.  A caller who does not know the largest
+ * cell and the largest row total measures them with one streaming read of X:
+ *     out[0] = max(out[0], max_ik x_ik),  out[1] = max(out[1], max_i sum_k max(x_ik, 0))
+ * (device words, max-accumulated: zero them first; negative cells are ignored here and reported
+ * by the statistics pass).
+ * ------------------------------------------------------------------------------------------- */
+int dme_bounds_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                         uint64_t* out /*[dev][2]*/, void* stream);
+int dme_bounds_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                         uint64_t* out /*[dev][2]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Statistics build.  Replaces CompressedRowData.appendRow (DE/dme.py:113-123) applied to every
  * row, plus the CLI's mean accumulator (DE/fdp.py:87-89), in one pass over the count matrix.
  *

@@ -484,3 +484,31 @@ def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype):
     exact = exact.astype(np.float64)
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), exact, rtol=1e-13)
     np.testing.assert_allclose(ref.init_acc, exact, rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["u16", "i32"])
+@pytest.mark.parametrize("N,K,pad", [(1, 1, 0), (300, 8, 0), (257, 1000, 0), (100, 1000, 24), (90, 13, 3),
+                                     (5000, 64, 0)])
+def test_bounds_pass(dtype, N, K, pad):
+    """dme_bounds_dense_*: largest cell and largest row total (positive parts), vector and scalar
+    layouts, padded rows; and add_dense without stated bounds sizes its histograms from it."""
+    from bayespy_amd import _lib
+    dev = _dev()
+    rng = np.random.default_rng(N + K + pad)
+    hi = 60000 if dtype == "u16" else 3_000_000
+    X = rng.integers(0, 50, size=(N, K + pad)).astype(np.int64)
+    X[rng.integers(0, N), rng.integers(0, K)] = hi
+    if dtype == "i32" and N > 1:
+        X[0, 0] = -7  # ignored here, reported by the statistics pass
+    Xd = _to_dev(X, dtype)[:, :K]
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    fn = _lib.lib().dme_bounds_dense_u16 if dtype == "u16" else _lib.lib().dme_bounds_dense_i32
+    _lib.check(fn(Xd.data_ptr(), N, K, Xd.stride(0), out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    pos = np.maximum(X[:, :K], 0)
+    assert out.cpu().tolist() == [int(pos.max()), int(pos.sum(axis=1).max())]
+    if not (dtype == "i32" and N > 1):
+        st = dev.DeviceStats(K)
+        st.add_dense(Xd)
+        info = st.check()
+        assert info["max_count"] == int(pos.max()) and info["max_total"] == int(pos.sum(axis=1).max())
+        assert st.nbins == int(pos.max()) + 1 and st.tbins == int(pos.sum(axis=1).max()) + 1
