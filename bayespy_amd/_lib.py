@@ -32,6 +32,7 @@ SIGNATURES = {
     "dme_stats_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dme_bounds_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_bounds_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_bounds_csr_i32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "dme_stats_csr_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "dme_stats_csr_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64,
                                  _vp]),

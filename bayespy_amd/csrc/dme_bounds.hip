@@ -87,7 +87,60 @@ int bounds_dense(const T* X, long long N, long long K, long long ld, u64* out, v
     return DME_OK;
 }
 
+// CSR rows: a wave takes 64 consecutive rows, one per lane when they are short (the bag-of-words
+// case: tens of entries), and walks long rows together.
+__global__ __launch_bounds__(256) void bounds_csr_kernel(const long long* rowptr, const int* vals,
+                                                         long long N, long long nnz, u64* out) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    u32 mc = 0;
+    u64 mt = 0;
+    for (long long r0 = wave0 * 64; r0 < N; r0 += nwaves * 64) {
+        const long long r = r0 + lane;
+        long long p0 = 0, p1 = 0;
+        if (r < N) {
+            p0 = rowptr[r];
+            p1 = rowptr[r + 1];
+            if (p0 < 0) p0 = 0;
+            if (p1 > nnz) p1 = nnz;  // an inconsistent rowptr is reported by the statistics pass
+        }
+        u64 s = 0;
+        for (long long p = p0; p < p1; ++p) {
+            const int v = vals[p];
+            if (v > 0) {
+                s += (u64)v;
+                mc = (u32)v > mc ? (u32)v : mc;
+            }
+        }
+        mt = s > mt ? s : mt;
+    }
+    const u64 m = dme_wave_max_u64((u64)mc);
+    const u64 t = dme_wave_max_u64(mt);
+    if (lane == 0) {
+        if (m) atomicMax(&out[0], m);
+        if (t) atomicMax(&out[1], t);
+    }
+}
+
 }  // namespace
+
+extern "C" int dme_bounds_csr_i32(const int64_t* rowptr, const int32_t* vals, int64_t N,
+                                  int64_t nnz, uint64_t* out, void* stream) {
+    DME_REQUIRE(N >= 0 && nnz >= 0, "bad shape N=%lld nnz=%lld", (long long)N, (long long)nnz);
+    DME_REQUIRE(out != nullptr, "null output pointer");
+    if (N == 0 || nnz == 0) return DME_OK;
+    DME_REQUIRE(rowptr && vals, "null CSR pointer");
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    long long waves = (N + 63) / 64;
+    if (waves > (long long)cus * 64) waves = (long long)cus * 64;
+    hipLaunchKernelGGL(bounds_csr_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const long long*)rowptr, vals, (long long)N,
+                       (long long)nnz, (u64*)out);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
 
 extern "C" int dme_bounds_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,
                                     uint64_t* out, void* stream) {

@@ -378,12 +378,14 @@ class DeviceStats:
             return self
         if colidx.numel() != vals.numel():
             raise ValueError("colidx and vals differ in length")
-        if max_count is None:
-            max_count = int(vals.max()) if vals.numel() else 0
-        if max_total is None:
-            cs = torch.zeros(vals.numel() + 1, dtype=torch.int64, device=self.device)
-            cs[1:] = torch.cumsum(vals.to(torch.int64), 0)
-            max_total = int((cs[rowptr[1:]] - cs[rowptr[:-1]]).max())
+        if max_count is None or max_total is None:  # measured: one pass over rowptr / vals
+            with _on(self.device):
+                out = torch.zeros(2, dtype=torch.int64, device=self.device)
+                _lib.check(_lib.lib().dme_bounds_csr_i32(_ptr(rowptr), _ptr(vals), N, vals.numel(),
+                                                         _ptr(out), _stream()))
+                mc, mt = (int(v) for v in out.cpu())
+            max_count = mc if max_count is None else max_count
+            max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
         nnz = colidx.numel()
         with _on(self.device):

@@ -56,6 +56,9 @@ int dme_bounds_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int6
                          uint64_t* out /*[dev][2]*/, void* stream);
 int dme_bounds_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
                          uint64_t* out /*[dev][2]*/, void* stream);
+/* the same for CSR rows (largest stored value, largest sum of a row's positive values) */
+int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals /*[dev][nnz]*/,
+                       int64_t N, int64_t nnz, uint64_t* out /*[dev][2]*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Statistics build.  Replaces CompressedRowData.appendRow (DE/dme.py:113-123) applied to every

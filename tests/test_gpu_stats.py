@@ -512,3 +512,25 @@ def test_bounds_pass(dtype, N, K, pad):
         info = st.check()
         assert info["max_count"] == int(pos.max()) and info["max_total"] == int(pos.sum(axis=1).max())
         assert st.nbins == int(pos.max()) + 1 and st.tbins == int(pos.sum(axis=1).max()) + 1
+
+
+def test_bounds_pass_csr():
+    """dme_bounds_csr_i32 against numpy on ragged rows (empty rows, one long row, a negative value)."""
+    from bayespy_amd import _lib
+    rng = np.random.default_rng(11)
+    N, K = 5000, 300
+    lens = rng.integers(0, 40, size=N)
+    lens[17] = 9000
+    rowptr = np.zeros(N + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    nnz = int(rowptr[-1])
+    vals = rng.integers(0, 9, size=nnz).astype(np.int32)
+    vals[5] = -3
+    vals[nnz // 2] = 123456
+    pos = np.maximum(vals, 0).astype(np.int64)
+    tot = np.add.reduceat(np.concatenate([pos, [0]]), rowptr[:-1]) * (lens > 0)
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    rp, vd = torch.from_numpy(rowptr).cuda(), torch.from_numpy(vals).cuda()
+    _lib.check(_lib.lib().dme_bounds_csr_i32(rp.data_ptr(), vd.data_ptr(), N, nnz, out.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    assert out.cpu().tolist() == [int(pos.max()), int(tot.max())]
