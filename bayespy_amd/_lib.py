@@ -47,6 +47,7 @@ SIGNATURES = {
     "dme_shard_unpack": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "dme_solver_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "dme_eval": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dme_eval_noalloc": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp, _vp, _vp]),
     "dme_predicted_step": (_int, [_f64, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_predicted_step_alt": (_int, [_f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_solve": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _i64, _vp,

@@ -21,6 +21,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "dme_common.h"
 
 namespace {
@@ -917,6 +919,68 @@ extern "C" int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, 
     const Prior pr{0.0, beta, W, has_W ? 1 : 0, 0};
     return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
                      workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dme_eval_noalloc: dme_eval for callers that cannot allocate (HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc).  The solver workspace that dme_eval takes as an argument
+// (control block, segment table, per-segment partial sums, six K-vectors) lives in a file-scope
+// device array instead.  Every GPU holds its own copy of the array at its own address, so the
+// address is looked up once per device with hipGetSymbolAddress (with that device current) and only
+// that pointer - never the array's name, which is a host-side stand-in - is handed to kernels.
+// Nothing in it has to start at zero: setup_kernel writes the whole control block and the segment
+// table, eval_kernel writes every partial that the gather later reads.  Calls that overlap on one
+// GPU (two streams, two threads) race on the array.
+// ---------------------------------------------------------------------------------------------
+constexpr long long kNoAllocScratchBytes = DME_NOALLOC_SCRATCH_BYTES;  // 8 MiB per GPU, held until the process ends
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (looked up on the first call per device).
+int noalloc_scratch(void** out) {
+    int dev = 0;
+    DME_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices)
+        return dme_set_error(DME_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        DME_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p || ((uintptr_t)p % 256) != 0)
+            return dme_set_error(DME_ERR_HIP, "hipGetSymbolAddress(scratch) returned %p", p);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DME_OK;
+}
+
+}  // namespace
+
+extern "C" int dme_eval_noalloc(const double* Uf, int64_t ldU, const int64_t* lenU,
+                                const double* Vf, int64_t capV, const int64_t* lenV, int64_t K,
+                                const double* alpha, double hyperprior, double* out_scalars,
+                                double* out_grad, double* out_hdiag, void* stream) {
+    DME_REQUIRE(K >= 1 && ldU >= 1 && capV >= 1, "bad shape K=%lld ldU=%lld capV=%lld",
+                (long long)K, (long long)ldU, (long long)capV);
+    DME_REQUIRE(K < (1LL << 31) && ldU < (1LL << 31) && capV < (1LL << 31), "shape too large");
+    const long long need = carve(nullptr, K, ldU, capV).bytes;
+    if (need > kNoAllocScratchBytes)
+        return dme_set_error(DME_ERR_WORKSPACE,
+                             "dme_eval_noalloc: K=%lld ldU=%lld capV=%lld needs %lld bytes of solver "
+                             "workspace, the static scratch holds %lld; use dme_eval with a workspace",
+                             (long long)K, (long long)ldU, (long long)capV, need,
+                             kNoAllocScratchBytes);
+    void* ws = nullptr;
+    int rc = noalloc_scratch(&ws);
+    if (rc) return rc;
+    const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
+    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
+                     ws, kNoAllocScratchBytes, stream);
 }
 
 extern "C" int dme_predicted_step(double hconst, const double* hdiag, const double* grad, int64_t K,

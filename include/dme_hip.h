@@ -202,6 +202,21 @@ int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* V
              double* out_hdiag /*[dev][K]*/, void* workspace, int64_t workspace_bytes,
              void* stream);
 
+/* dme_eval for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference: it exists for
+ * those callers only.  Same arguments, kernels and results (bit for bit) as dme_eval with the
+ * scalar hyperprior, minus the workspace: the solver workspace is a static device array inside the
+ * library, DME_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.  Shapes whose
+ * dme_solver_workspace_bytes(K, ldU, capV) exceeds that are rejected with DME_ERR_WORKSPACE (use
+ * dme_eval).  Calls no hipMalloc / hipFree / allocating routine; the first call on a device looks
+ * up the array's address there (hipGetSymbolAddress).  All calls on one GPU share the array:
+ * calls that overlap on one GPU (other streams or threads) race - serialise them.  Asynchronous. */
+#define DME_NOALLOC_SCRATCH_BYTES (8LL << 20)
+int dme_eval_noalloc(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                     int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                     double hyperprior, double* out_scalars /*[dev][4]*/,
+                     double* out_grad /*[dev][K]*/, double* out_hdiag /*[dev][K]*/, void* stream);
+
 /* getPredictedStep (DE/dme.py:67-72) and getPredictedStepAlt (:76-80) on device vectors.
  * status [dev][1] int64: 0 ok, DME_ERR_ZERO_DIVISION if the reference would divide by zero. */
 int dme_predicted_step(double hconst, const double* hdiag /*[dev]*/, const double* grad /*[dev]*/,
