@@ -45,6 +45,9 @@ SIGNATURES = {
     "dme_shard_message_words": (_i64, [_i64, _i64, _i64, _i64]),
     "dme_shard_pack": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_shard_unpack": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "dme_shard_message_words32": (_i64, [_i64, _i64, _i64, _i64]),
+    "dme_shard_pack32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_shard_unpack32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dme_solver_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "dme_eval": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dme_eval_noalloc": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp, _vp, _vp]),

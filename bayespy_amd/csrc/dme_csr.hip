@@ -50,9 +50,9 @@ constexpr long long CSR_SMALL_NNZ = 1 << 15;
 // atomics path (small inputs, no workspace)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr, const int* colidx,
-                                                        const int* vals, long long N, long long K,
-                                                        u64* hist, long long nbins, u64* histV,
-                                                        long long tbins, double* init_acc,
+                                                        const int* vals, long long N, long long nnz,
+                                                        long long K, u64* hist, long long nbins,
+                                                        u64* histV, long long tbins, double* init_acc,
                                                         u64* status) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -63,6 +63,10 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
     u64 nrows = 0;
     for (long long i = wave0; i < N; i += nwaves) {
         const long long p0 = rowptr[i], p1 = rowptr[i + 1];
+        if (p0 < 0 || p1 < p0 || p1 > nnz) {  // malformed rowptr: the row is not touched (wave-uniform)
+            if (lane == 0) atomicAdd(&status[6], 1ULL);
+            continue;
+        }
         u64 s = 0;
         for (long long p = p0 + lane; p < p1; p += 64) {
             const int v = vals[p];
@@ -199,12 +203,17 @@ int plan_csr(long long N, long long nnz, long long K, long long nbins, CsrPlan* 
     return DME_OK;
 }
 
-// counts[g][b] = entries of slab g whose column lies in bucket b
+// counts[g][b] = entries of slab g whose column lies in bucket b.
+// Before it reads colidx a workgroup checks its slab's row pointers: rowptr[r0] >= 0, non-decreasing
+// up to rowptr[r1] <= nnz.  A slab that fails raises status[6] and counts nothing; every later
+// kernel of the pass returns at once when status[6] is set, so a malformed rowptr (more entries
+// than the caller's nnz, or rows that run backwards) never turns into an out-of-bounds access.
 __global__ __launch_bounds__(CSR_BLOCK) void csr_count_kernel(const long long* rowptr,
                                                               const int* colidx, long long N,
-                                                              long long K, long long rows_per_slab,
-                                                              int sh, int NB, int copies,
-                                                              u32* counts) {
+                                                              long long nnz, long long K,
+                                                              long long rows_per_slab, int sh,
+                                                              int NB, int copies, u32* counts,
+                                                              u64* status) {
     extern __shared__ u32 cnt[];  // [copies][NB]
     const int tid = threadIdx.x;
     for (int i = tid; i < copies * NB; i += CSR_BLOCK) cnt[i] = 0;
@@ -212,6 +221,16 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_count_kernel(const long long* r
     const long long r0 = (long long)blockIdx.x * rows_per_slab;
     long long r1 = r0 + rows_per_slab;
     if (r1 > N) r1 = N;
+    bool bad = false;
+    for (long long r = r0 + tid; r < r1; r += CSR_BLOCK) {
+        const long long a0 = rowptr[r], a1 = rowptr[r + 1];
+        if (a0 < 0 || a1 < a0 || a1 > nnz) bad = true;
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {  // block-uniform
+        if (tid == 0) atomicAdd(&status[6], 1ULL);
+        for (int b = tid; b < NB; b += CSR_BLOCK) counts[(long long)blockIdx.x * NB + b] = 0;
+        return;
+    }
     if (r0 < r1) {
         const long long e0 = rowptr[r0], e1 = rowptr[r1];
         u32* mine = cnt + ((tid >> 6) & (copies - 1)) * NB;
@@ -404,8 +423,10 @@ __global__ __launch_bounds__(CSR_SBLOCK, 4) void csr_scatter_kernel(CsrArgs a) {
     long long r1 = r0 + a.rows_per_slab;
     if (r1 > a.N) r1 = a.N;
     if (r0 >= r1) return;  // uniform: nothing was written yet
-    if (a.start[a.NB] > a.capacity) {  // rowptr spans more entries than the caller's nnz: no writes
-        if (g == 0 && tid == 0) atomicAdd(&a.status[6], 1ULL);
+    // a slab whose row pointers failed the count kernel's check (or an earlier call on these status
+    // words did): nothing is read or written
+    if (a.status[6] != 0 || a.start[a.NB] > a.capacity) {
+        if (g == 0 && tid == 0 && a.status[6] == 0) atomicAdd(&a.status[6], 1ULL);
         return;
     }
     const u32 cmask = (1u << a.sh) - 1;
@@ -682,6 +703,7 @@ struct BucketArgs {
     int sh, NB, BL, W, AC;
     u64* hist;
     double* init_acc;
+    const u64* status;
     char* images;           // [NB + W] LDS images: AC x CB fp64 accumulators, then CB x BL counters
     long long image_bytes;  // = 8*AC*CB + 4*CB*BL (a multiple of 16)
 };
@@ -703,7 +725,7 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_bucket_kernel(BucketArgs a) {
     const u32 acmask = (u32)a.AC - 1;
     const int tid = threadIdx.x;
     const u64 total = a.start[a.NB];
-    if (total > a.capacity) return;  // flagged by the scatter kernel
+    if (total > a.capacity || a.status[6] != 0) return;  // malformed rowptr: flagged, nothing counted
     const u64 piece = csr_piece(total, a.W);
     u64 pos = piece * blockIdx.x;
     u64 end = pos + piece;
@@ -773,7 +795,7 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_bucket_kernel(BucketArgs a) {
 __global__ __launch_bounds__(CSR_BLOCK) void csr_reduce_kernel(BucketArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const u64 s0 = a.start[b], s1 = a.start[b + 1];
-    if (s1 == s0 || a.start[a.NB] > a.capacity) return;
+    if (s1 == s0 || a.start[a.NB] > a.capacity || a.status[6] != 0) return;
     const int CB = 1 << a.sh;
     const u64 piece = csr_piece(a.start[a.NB], a.W);
     const int w_lo = (int)(s0 / piece), w_hi = (int)((s1 - 1) / piece);
@@ -850,9 +872,9 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
         long long waves = N < (long long)cus * 32 ? N : (long long)cus * 32;
         long long grid = (waves + 3) / 4;
         hipLaunchKernelGGL(stats_csr_kernel, dim3((unsigned)grid), dim3(256), 0, s,
-                           (const long long*)rowptr, colidx, vals, (long long)N, (long long)K,
-                           (u64*)hist, (long long)nbins, (u64*)histV, (long long)tbins, init_acc,
-                           (u64*)status);
+                           (const long long*)rowptr, colidx, vals, (long long)N, (long long)nnz,
+                           (long long)K, (u64*)hist, (long long)nbins, (u64*)histV, (long long)tbins,
+                           init_acc, (u64*)status);
         DME_HIP_CHECK(hipGetLastError());
         return DME_OK;
     }
@@ -865,8 +887,8 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     uint2* entries = (uint2*)(ws + p.off_entries);
 
     hipLaunchKernelGGL(csr_count_kernel, dim3(p.G), dim3(CSR_BLOCK), (size_t)p.copies * p.NB * 4, s,
-                       (const long long*)rowptr, colidx, (long long)N, (long long)K,
-                       p.rows_per_slab, p.sh, p.NB, p.copies, counts);
+                       (const long long*)rowptr, colidx, (long long)N, (long long)nnz, (long long)K,
+                       p.rows_per_slab, p.sh, p.NB, p.copies, counts, (u64*)status);
     hipLaunchKernelGGL(csr_offsets_kernel, dim3((p.NB + 63) / 64), dim3(CSR_BLOCK), 0, s, counts,
                        p.G, p.NB, rel, tot);
     hipLaunchKernelGGL(csr_bucket_scan_kernel, dim3(1), dim3(CSR_BLOCK), 0, s, tot, p.NB, start);
@@ -891,7 +913,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     BucketArgs bk{};
     bk.entries = entries; bk.start = start; bk.K = K; bk.nbins = nbins; bk.capacity = (u64)nnz;
     bk.sh = p.sh; bk.NB = p.NB; bk.BL = p.BL; bk.W = p.W; bk.AC = p.AC;
-    bk.hist = (u64*)hist; bk.init_acc = init_acc;
+    bk.hist = (u64*)hist; bk.init_acc = init_acc; bk.status = (const u64*)status;
     const size_t lds_bucket = 8 * (size_t)p.AC * p.CB + 4 * (size_t)p.CB * p.BL;
     bk.images = ws + p.off_images;
     bk.image_bytes = (long long)lds_bucket;

@@ -53,7 +53,8 @@ struct Ctrl {
     double learnRate;
     double A_trial;
     double hconst_cur;
-    double pad[2];
+    long long fragile;  // accept / reject decisions taken on |trial loss - current loss| <= ~4 ulp
+    double pad;
 };
 static_assert(sizeof(Ctrl) % 16 == 0, "Ctrl must stay 16-byte sized");
 
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
         Ctrl* c = w.ctrl;
         c->done = 0; c->phase = phase; c->count = 0; c->n_evals = 0; c->exit_reason = 0;
         c->error = 0; c->launches = 0; c->branch = 0; c->currentLoss = 0.0; c->learnRate = 1.0;
-        c->hconst_cur = 0.0;
+        c->hconst_cur = 0.0; c->fragile = 0;
     }
     for (long long k = tid; k < K; k += STEP_BLOCK) w.alpha_trial[k] = alpha[k];
     __syncthreads();
@@ -582,6 +583,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
     long long count = c->count;
     long long n_evals = c->n_evals;
     long long branch = c->branch;
+    long long fragile = c->fragile;
 
     double lossT = INFINITY;
     double hconstT = 0.0;
@@ -591,6 +593,12 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
         lossT = loss_from<CPT>(G, A, pr);
         hconstT = G.t2;
         n_evals += 1;
+        // SURVEY 7 "parity-fragile": the comparisons of DE/dme.py:160 / :176 are about to be taken on
+        // a loss difference of a few ulp, i.e. on rounding noise that a different summation order
+        // (the reference's sequential sums) may resolve the other way
+        if (phase != PH_INIT &&
+            fabs(__dsub_rn(lossT, currentLoss)) <= 4.0 * 2.220446049250313e-16 * fabs(currentLoss))
+            fragile += 1;
     }
 
     auto finish = [&](long long reason, long long err) {
@@ -603,6 +611,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
             result[6] = 1;  // done: what the host polls
             result[4] = c->launches + 1;
             result[5] = __double_as_longlong(currentLoss);
+            result[7] = fragile;
             if (final_loss) final_loss[0] = currentLoss;
         }
     };
@@ -610,6 +619,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
         if (tid == 0) {
             c->phase = new_phase; c->count = count; c->n_evals = n_evals;
             c->currentLoss = currentLoss; c->learnRate = learnRate; c->branch = branch;
+            c->fragile = fragile;
             c->launches += 1;
         }
     };

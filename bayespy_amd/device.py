@@ -165,13 +165,20 @@ class DeviceUV:
             return float(s[0]), float(s[1]), grad.cpu().numpy(), hdiag.cpu().numpy(), float(s[3])
 
     # -- the Newton loop (DE/dme.py:126-190) ----------------------------------------------------
-    def solve(self, init_alphas, iterations, hyperprior=0.0, trace_alphas=True, Beta=None, W=None):
+    def solve(self, init_alphas, iterations, hyperprior=0.0, trace_alphas=True, Beta=None, W=None,
+              consume_init=False):
         """Runs findDirichletPriors on the device.  Returns a dict: alpha (np.float64[K]),
         exit (1/2/3), n_iters, n_evals, final_loss, trace (n_iters x 4: loss, gradSq, branch,
-        learnRate), trace_alpha (n_iters x K or None).  With Beta / W: CPT/dme.py:156-219."""
+        learnRate), trace_alpha (n_iters x K or None).  With Beta / W: CPT/dme.py:156-219.
+        `consume_init`: a float64 device tensor passed as init_alphas is overwritten with the result
+        instead of being copied first (the caller gives it up; saves a device copy)."""
         iterations = int(iterations)
         with _on(self.device):
-            if isinstance(init_alphas, torch.Tensor):
+            if (consume_init and isinstance(init_alphas, torch.Tensor)
+                    and init_alphas.device == self.device and init_alphas.dtype == torch.float64
+                    and init_alphas.is_contiguous()):
+                a = init_alphas.detach()
+            elif isinstance(init_alphas, torch.Tensor):
                 a = init_alphas.detach().to(device=self.device, dtype=torch.float64).clone()
             else:
                 a = torch.as_tensor(np.array(init_alphas, dtype=np.float64)).to(self.device)
@@ -227,6 +234,8 @@ class SolveResult(dict):
             "n_evals": int(res[2]),
             "launches": int(res[4]),
             "final_loss": struct.unpack("d", struct.pack("q", res[5]))[0],
+            # accept / reject decisions taken on a loss difference of <= ~4 ulp
+            "fragile_decisions": int(res[7]),
         })
 
     def __missing__(self, key):
@@ -425,7 +434,8 @@ class DeviceStats:
         else:
             st = self.status.cpu().numpy()
         if st[6]:
-            raise ValueError("CSR input inconsistent: rowptr spans more entries than colidx / vals hold")
+            raise ValueError("CSR input inconsistent: rowptr is negative, decreasing, or spans more "
+                             "entries than colidx / vals hold")
         if st[3]:
             raise ValueError(f"{int(st[3])} negative counts (or column indices out of range)")
         if st[1] or st[2]:
@@ -440,16 +450,19 @@ class DeviceStats:
         return int(self.status[0].cpu())
 
     # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
-    def allreduce(self, group=None, same_extents=False):
+    def allreduce(self, group=None, same_extents=False, rows_bound=None):
         """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs): one integer SUM
         all-reduce, see parallel.allreduce_stats_tensors.  `same_extents=True` when every rank
-        passed the same max_count / max_total (no extent agreement round, no host sync).  After
+        passed the same max_count / max_total (no extent agreement round, no host sync);
+        `rows_bound` (the same on every rank): an upper bound on the rows of the whole job - below
+        2^32 the message travels in 32-bit words, half the bytes.  After
         it every rank holds the global statistics and solves redundantly; there is no
         per-iteration communication."""
         from .parallel import allreduce_stats_tensors
         (self.hist, self.histV, self.status, self.init_acc, self.nbins,
          self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
-                                               self.K, self.nbins, self.tbins, group, same_extents)
+                                               self.K, self.nbins, self.tbins, group, same_extents,
+                                               rows_bound)
         return self
 
     def merge_(self, other):

@@ -37,7 +37,7 @@ def grow_vec(v, new_len):
 
 
 def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
-                            same_extents=False):
+                            same_extents=False, rows_bound=None):
     """All-reduces one rank's partial statistics.  Tensors may live on any device the process
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
@@ -51,7 +51,12 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     written and read by two HIP kernels (dme_shard_pack / dme_shard_unpack); host tensors (the
     gloo tests) build the same message with torch.  `same_extents` (every rank built its histograms
     with the same max_count / max_total) skips the MAX all-reduce that otherwise agrees the
-    extents first."""
+    extents first.
+
+    `rows_bound`: an upper bound on the rows of the whole job that EVERY rank passes alike.  Below
+    2^32 no bin can need more than 32 bits, and the message travels in 32-bit words (bins one word
+    each, the rest as (lo, hi) pairs; dme_shard_pack32 / dme_shard_unpack32): half the bytes on the
+    wire (SURVEY 8e "uint32 if N < 2^32")."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return hist, histV, status, init_acc, nbins, tbins
@@ -64,6 +69,8 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
         hist = grow_hist(hist, K, nbins, nb)
         histV = grow_vec(histV, tb)
     nh, nv = hist.numel(), histV.numel()
+    if rows_bound is not None and 0 <= int(rows_bound) < (1 << 32):
+        return _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, rank)
     nmsg = nh + nv + 8 + world * (2 + K)
     if hist.is_cuda:
         from . import _lib
@@ -98,3 +105,51 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     for r in range(1, world):  # fixed order: bit-identical on every rank
         acc += parts[r]
     return msg[:nh], msg[nh:nh + nv], out_status, acc, nb, tb
+
+
+def _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, rank):
+    """The 32-bit form of the message (include/dme_hip.h, dme_shard_pack32): int32 SUM all-reduce."""
+    import torch.distributed as dist
+    nh, nv = hist.numel(), histV.numel()
+    nmsg = nh + nv + 2 * (8 + world * (2 + K))
+    if hist.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        L = _lib.lib()
+        with _on(hist.device):
+            msg = torch.empty(nmsg, dtype=torch.int32, device=hist.device)
+            _lib.check(L.dme_shard_pack32(_ptr(hist), nh, _ptr(histV), nv, _ptr(status),
+                                          _ptr(init_acc), K, rank, world, _ptr(msg), _stream()))
+            if dist.get_backend(group) == "gloo":
+                torch.cuda.current_stream(msg.device).synchronize()  # see allreduce_stats_tensors
+            dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
+            out = torch.empty(nh + nv + 8, dtype=torch.int64, device=hist.device)
+            acc = torch.empty(K, dtype=torch.float64, device=hist.device)
+            _lib.check(L.dme_shard_unpack32(_ptr(msg), nh, nv, K, world, _ptr(out),
+                                            out.data_ptr() + 8 * nh, out.data_ptr() + 8 * (nh + nv),
+                                            _ptr(acc), _stream()))
+        return out[:nh], out[nh:nh + nv], out[nh + nv:], acc, nb, tb
+    # host tensors (gloo tests): the same message with torch
+    cap = 0xFFFFFFFF // world
+    tail = torch.zeros(8 + world * (2 + K), dtype=torch.int64)
+    tail[:8] = torch.clamp(status, max=cap)
+    tail[4:6] = 0
+    slots = tail[8:].view(world, 2 + K)
+    slots[rank, :2] = status[4:6]
+    slots[rank, 2:] = init_acc.view(torch.int64)
+    lohi = torch.stack([tail & 0xFFFFFFFF, (tail >> 32) & 0xFFFFFFFF], dim=1).reshape(-1)
+    msg = torch.cat([hist, histV, lohi])  # int64 holding 32-bit words
+    msg = (msg & 0xFFFFFFFF).to(torch.int64)
+    msg32 = torch.where(msg >= (1 << 31), msg - (1 << 32), msg).to(torch.int32)
+    dist.all_reduce(msg32, op=dist.ReduceOp.SUM, group=group)
+    words = msg32.to(torch.int64) & 0xFFFFFFFF
+    t = words[nh + nv:].view(-1, 2)
+    tail = t[:, 0] | (t[:, 1] << 32)
+    out_status = tail[:8].clone()
+    slots = tail[8:].view(world, 2 + K)
+    out_status[4:6] = slots[:, :2].max(dim=0).values
+    parts = slots[:, 2:].contiguous().view(torch.float64)
+    acc = parts[0].clone()
+    for r in range(1, world):  # fixed order: bit-identical on every rank
+        acc += parts[r]
+    return words[:nh].clone(), words[nh:nh + nv].clone(), out_status, acc, nb, tb

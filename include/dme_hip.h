@@ -74,7 +74,8 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  *     [0] rows processed        [1] cells with count >= nbins (NOT counted: result incomplete)
  *     [2] rows with total >= tbins (NOT counted)              [3] negative cells (i32 only)
  *     [4] max count seen        [5] max row total seen
- *     [6] CSR only: rowptr spans more entries than the nnz passed (nothing was counted)
+ *     [6] CSR only: malformed rowptr - negative, decreasing, or spanning more entries than the nnz
+ *         passed (the partitioned pass then counts nothing; the atomics pass skips such rows)
  * The caller must check status[1..3] == 0 and status[6] == 0 (they are data errors, reported after the fact so
  * that the pass stays asynchronous).
  *
@@ -182,6 +183,23 @@ int dme_shard_pack(const uint64_t* hist /*[dev]*/, int64_t nh, const uint64_t* h
 int dme_shard_unpack(uint64_t* msg /*[dev]*/, int64_t nh, int64_t nv, int64_t K, int64_t world,
                      double* init_acc /*[dev][K] out*/, void* stream);
 
+/* The same message in 32-bit words, for jobs of fewer than 2^32 rows in all (no bin can then exceed
+ * 32 bits; SURVEY 8e "uint32 if N < 2^32"): hist | histV as one word per bin, then status[8] and the
+ * slots as (lo, hi) word pairs - half the bytes on the wire.  The caller promises the row bound; the
+ * additive status words are saturated at (2^32 - 1) / world per rank.  The all-reduce is an int32
+ * SUM.  dme_shard_unpack32 widens the bins into hist64 / histV64 (what dme_suffix_scan reads),
+ * writes status[8] with the maxima over ranks, and init_acc as dme_shard_unpack does.
+ * dme_shard_message_words32 = nh + nv + 2 * (8 + world*(2 + K)). */
+int64_t dme_shard_message_words32(int64_t nh, int64_t nv, int64_t K, int64_t world);
+int dme_shard_pack32(const uint64_t* hist /*[dev]*/, int64_t nh, const uint64_t* histV /*[dev]*/,
+                     int64_t nv, const uint64_t* status /*[dev][8]*/,
+                     const double* init_acc /*[dev][K]*/, int64_t K, int64_t rank, int64_t world,
+                     uint32_t* msg /*[dev]*/, void* stream);
+int dme_shard_unpack32(const uint32_t* msg /*[dev]*/, int64_t nh, int64_t nv, int64_t K,
+                       int64_t world, uint64_t* hist64 /*[dev][nh] out*/,
+                       uint64_t* histV64 /*[dev][nv] out*/, uint64_t* status /*[dev][8] out*/,
+                       double* init_acc /*[dev][K] out*/, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Solver.  U is dense-padded fp64: U[k][n] = Uf[k*ldU + n] for n < lenU[k]; V = Vf[0..lenV).
  * lenU [K] and lenV [1] are device arrays (as written by dme_suffix_scan).
@@ -236,7 +254,9 @@ int dme_predicted_step_alt(double hconst, const double* hdiag, const double* gra
  *   result [dev][8] int64: [0] exit reason (1 = small gradient, 2 = small learn rate,
  *       3 = max iterations), [1] iterations, [2] loss evaluations, [3] error
  *       (0 / DME_ERR_ZERO_DIVISION / DME_ERR_MATH_DOMAIN), [4] evaluation launches used,
- *       [5] the bits of final_loss (double), [6] done flag.
+ *       [5] the bits of final_loss (double), [6] done flag, [7] "parity-fragile" count: accept /
+ *       reject decisions (DE/dme.py:160, :176) taken on |trial loss - current loss| <= ~4 ulp, i.e.
+ *       on rounding noise that the reference's sequential sums may resolve the other way.
  *   result_host [host][8] or NULL: a copy of `result` in host memory, valid on return (saves the
  *       caller a device-to-host copy).
  *   final_loss [dev][1] or NULL: getTotalLoss at the returned priors.

@@ -32,7 +32,7 @@ def _hist_of(X, K):
     return hist, histV, status, acc, nb, tb
 
 
-def _worker(rank, world, port, X, K, out, same_extents=False):
+def _worker(rank, world, port, X, K, out, same_extents=False, rows_bound=None):
     sys.path.insert(0, ROOT)
     from bayespy_amd.parallel import allreduce_stats_tensors, shard_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -47,7 +47,7 @@ def _worker(rank, world, port, X, K, out, same_extents=False):
         nb, tb = 64, 512
     res = allreduce_stats_tensors(torch.from_numpy(hist.reshape(-1)), torch.from_numpy(histV),
                                   torch.from_numpy(status), torch.from_numpy(acc), K, nb, tb,
-                                  same_extents=same_extents)
+                                  same_extents=same_extents, rows_bound=rows_bound)
     h, v, st, a, nb2, tb2 = res
     out[rank] = (h.view(K, nb2).numpy().copy(), v.numpy().copy(), st.numpy().copy(),
                  a.numpy().copy(), nb2, tb2)
@@ -102,6 +102,26 @@ def test_allreduce_with_agreed_extents_is_one_collective():
     for r in range(world):
         h, v, st, a, nb2, tb2 = out[r]
         assert (nb2, tb2) == (64, 512)
+        assert np.array_equal(h[:, :nb], hist) and not h[:, nb:].any()
+        assert np.array_equal(v[:tb], histV) and not v[tb:].any()
+        assert st[0] == N and st[4] == status[4] and st[5] == status[5]
+        np.testing.assert_allclose(a, acc, rtol=1e-13)
+        assert np.array_equal(a, out[0][3])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_in_32_bit_words_is_exact(world):
+    """rows_bound < 2^32: the message travels in 32-bit words; same results, including
+    a bin count and an accumulator bit pattern with the top bit of a 32-bit word set."""
+    rng = np.random.default_rng(13)
+    K, N = 4, 40
+    X = rng.integers(0, 6, size=(N, K))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), X, K, out, True, N), nprocs=world, join=True)
+    hist, histV, status, acc, nb, tb = _hist_of(X, K)
+    for r in range(world):
+        h, v, st, a, nb2, tb2 = out[r]
         assert np.array_equal(h[:, :nb], hist) and not h[:, nb:].any()
         assert np.array_equal(v[:tb], histV) and not v[tb:].any()
         assert st[0] == N and st[4] == status[4] and st[5] == status[5]

@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, X, K, out):
+def _worker(rank, world, port, X, K, out, rows_bound=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from bayespy_amd import device
@@ -28,7 +28,11 @@ def _worker(rank, world, port, X, K, out):
     lo, hi = shard_rows(X.shape[0], rank, world)
     st = device.DeviceStats(K)
     st.add_dense(torch.from_numpy(np.ascontiguousarray(X[lo:hi])).cuda())
-    st.allreduce()
+    if rows_bound is None:
+        st.allreduce()
+    else:  # the 32-bit message needs agreed extents: size every rank's histograms alike first
+        st.reserve(int(X.max()), int(X.sum(axis=1).max()))
+        st.allreduce(same_extents=True, rows_bound=rows_bound)
     info = st.check()
     uv = st.finalize()
     U, V = uv.to_lists()
@@ -37,7 +41,8 @@ def _worker(rank, world, port, X, K, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_allreduce_then_identical_solve():
+@pytest.mark.parametrize("rows_bound", [None, 2000])
+def test_two_ranks_allreduce_then_identical_solve(rows_bound):
     import torch.multiprocessing as mp
     from conftest import load_golden
     fx = load_golden("dirmult_k1000")
@@ -48,7 +53,7 @@ def test_two_ranks_allreduce_then_identical_solve():
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, X, fx["K"], out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, X, fx["K"], out, rows_bound), nprocs=2, join=True)
     ref = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "cli"][0]
     for r in range(2):
         U, V, rows, alpha, n_iters = out[r]
@@ -113,3 +118,52 @@ def test_shard_pack_rejects_bad_rank():
     with pytest.raises(ValueError):
         _lib.check(_lib.lib().dme_shard_pack(z.data_ptr(), 2, z.data_ptr(), 2, z.data_ptr(),
                                              z.data_ptr(), 1, 3, 2, z.data_ptr(), 0))
+
+
+@pytest.mark.parametrize("world,K,nbins,tbins", [(3, 5, 4, 7), (8, 1000, 33, 65), (2, 1, 2, 2)])
+def test_shard_message_kernels_32_bit_words(world, K, nbins, tbins):
+    """dme_shard_pack32 / dme_shard_unpack32: every rank's message summed as int32 words (what the
+    all-reduce does), then unpacked: bins widened exactly, status words summed (maxima taken),
+    accumulators added in rank order bit for bit."""
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(world * 77 + K)
+    nh, nv = K * nbins, tbins
+    nmsg = nh + nv + 2 * (8 + world * (2 + K))
+    assert L.dme_shard_message_words32(nh, nv, K, world) == nmsg
+    stream = torch.cuda.current_stream().cuda_stream
+    total = torch.zeros(nmsg, dtype=torch.int32, device="cuda")
+    hsum, vsum = np.zeros(nh, dtype=np.int64), np.zeros(nv, dtype=np.int64)
+    accs, stats = [], []
+    top = (1 << 32) // world  # the sums reach beyond 2^31: the words are unsigned
+    for rank in range(world):
+        hist = rng.integers(0, top, size=nh, dtype=np.int64)
+        histV = rng.integers(0, top, size=nv, dtype=np.int64)
+        status = rng.integers(0, 1 << 28, size=8, dtype=np.int64)
+        acc = rng.random(K) * 10.0 ** rng.integers(-8, 8, size=K)
+        if rank == 0:
+            acc[0] = -acc[0]  # sign bit: the high word's top bit
+        hsum += hist
+        vsum += histV
+        accs.append(acc)
+        stats.append(status)
+        d = [torch.from_numpy(a).cuda() for a in (hist, histV, status, acc)]
+        msg = torch.full((nmsg,), -1, dtype=torch.int32, device="cuda")
+        _lib.check(L.dme_shard_pack32(d[0].data_ptr(), nh, d[1].data_ptr(), nv, d[2].data_ptr(),
+                                      d[3].data_ptr(), K, rank, world, msg.data_ptr(), stream))
+        total += msg  # int32 wrap-around = the all-reduce's arithmetic
+    out = torch.full((nh + nv + 8,), -1, dtype=torch.int64, device="cuda")
+    acc_out = torch.empty(K, dtype=torch.float64, device="cuda")
+    _lib.check(L.dme_shard_unpack32(total.data_ptr(), nh, nv, K, world, out.data_ptr(),
+                                    out.data_ptr() + 8 * nh, out.data_ptr() + 8 * (nh + nv),
+                                    acc_out.data_ptr(), stream))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:nh], hsum) and np.array_equal(got[nh:nh + nv], vsum)
+    st = got[nh + nv:]
+    summed = np.sum(stats, axis=0)
+    assert np.array_equal(st[:4], summed[:4]) and np.array_equal(st[6:], summed[6:])
+    assert st[4] == max(s[4] for s in stats) and st[5] == max(s[5] for s in stats)
+    ref = accs[0].copy()
+    for r in range(1, world):
+        ref = ref + accs[r]
+    assert np.array_equal(acc_out.cpu().numpy(), ref)

@@ -185,3 +185,16 @@ def test_cpython_port_matches_the_c_oracle(oracle):
     assert data.U == [list(map(int, u)) for u in ref.U]
     assert data.V == list(map(int, ref.V))
     assert acc == ref.init_acc.tolist()
+
+
+def test_numpy_structured_port_matches_the_c_oracle(oracle):
+    """oracle/np_port.py (the timing stand-in for the reference's NumPy port: float64 ndarrays grown
+    by np.append, a slice add per column per row) holds the same U/V values as the C oracle."""
+    from oracle import np_port
+    fx = load_golden("dirmult_k50")
+    X = fx["X"].astype(np.int32)[:400]
+    data, acc = np_port.build(X.tolist(), fx["K"])
+    ref = oracle.append_rows(X)
+    assert [u.tolist() for u in data.U] == [list(map(float, u)) for u in ref.U]
+    assert data.V.tolist() == list(map(float, ref.V))
+    assert acc == ref.init_acc.tolist()
