@@ -55,6 +55,10 @@ SIGNATURES = {
     "dme_predicted_step_alt": (_int, [_f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "dme_solve": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _i64, _vp,
                          _vp, _vp, _vp, _i64, _vp]),
+    "dme_solve_enqueue": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp, _vp,
+                                 _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_solve_finish": (_int, [_vp, _i64, _i64]),
+    "dme_solve_set_path": (_int, [_int]),
     "dme_parse_count_rows": (_i64, [ctypes.c_char_p, _i64]),
     "dme_parse_counts": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _int]),
     "dme_eval_cpt": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f64, _int, _vp, _vp, _vp,

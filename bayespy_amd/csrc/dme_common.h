@@ -152,3 +152,22 @@ __device__ __forceinline__ double dme_wave_sum_f64(double x) {
     r = __dadd_rn(r, dme_readlane_f64(x, 48));
     return r;
 }
+
+// DE/fdp.py:104-105 `priorSum = sum(priors) + 0.01`: the mean accumulators summed in a fixed order by
+// a BLOCK-thread workgroup (strided per thread, DPP inside a wave, waves in order).  Shared by
+// dme_cli_init_alphas and by the solver's set-up when it starts from the accumulators, so that both
+// give the same bits.  Every thread gets the result; wsum is LDS, BLOCK / 64 doubles.
+template <int BLOCK>
+__device__ __forceinline__ double dme_cli_prior_sum(const double* acc, long long K, double* wsum) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double s = 0.0;
+    for (long long k = tid; k < K; k += BLOCK) s = __dadd_rn(s, acc[k]);
+    s = dme_wave_sum_f64(s);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) tot = __dadd_rn(tot, wsum[w]);
+    __syncthreads();
+    return __dadd_rn(tot, 0.01);
+}

@@ -89,19 +89,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void suffix_scan_kernel(
 }
 
 // DE/fdp.py:104-108: priorSum = sum(priors) + 0.01; priors[i] = priors[i]/priorSum + 0.01
-__global__ __launch_bounds__(1024) void cli_init_kernel(const double* acc, long long K,
-                                                        double* alpha0) {
-    __shared__ double wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double s = 0.0;
-    for (long long k = tid; k < K; k += 1024) s = __dadd_rn(s, acc[k]);
-    s = dme_wave_sum_f64(s);
-    if (lane == 0) wsum[wave] = s;
-    __syncthreads();
-    double tot = 0.0;
-    for (int w = 0; w < 16; ++w) tot = __dadd_rn(tot, wsum[w]);
-    const double priorSum = __dadd_rn(tot, 0.01);
-    for (long long k = tid; k < K; k += 1024)
+constexpr int CLI_BLOCK = 512;  // the solver's set-up repeats this sum with the same workgroup shape
+__global__ __launch_bounds__(CLI_BLOCK) void cli_init_kernel(const double* acc, long long K,
+                                                             double* alpha0) {
+    __shared__ double wsum[CLI_BLOCK / 64];
+    const double priorSum = dme_cli_prior_sum<CLI_BLOCK>(acc, K, wsum);
+    for (long long k = threadIdx.x; k < K; k += CLI_BLOCK)
         alpha0[k] = __dadd_rn(__ddiv_rn(acc[k], priorSum), 0.01);
 }
 
@@ -127,7 +120,7 @@ extern "C" int dme_suffix_scan(const uint64_t* hist, int64_t K, int64_t nbins,
 extern "C" int dme_cli_init_alphas(const double* init_acc, int64_t K, double* alpha0,
                                    void* stream) {
     DME_REQUIRE(K >= 1 && init_acc && alpha0, "bad arguments");
-    hipLaunchKernelGGL(cli_init_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, init_acc,
+    hipLaunchKernelGGL(cli_init_kernel, dim3(1), dim3(CLI_BLOCK), 0, (hipStream_t)stream, init_acc,
                        (long long)K, alpha0);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;

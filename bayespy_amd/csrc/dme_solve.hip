@@ -118,6 +118,14 @@ struct Ws {
     double* alpha_trial;
     double* g_trial;
     double* d_trial;
+    // second copies of the state that crosses a launch, for the one-launch-per-evaluation path
+    // (iter_kernel): launch j reads copy j & 1 and writes the other
+    Ctrl* ctrl2;
+    Partial* part2;
+    double* alpha_cur2;
+    double* g_cur2;
+    double* d_cur2;
+    double* alpha_trial2;
     long long nseg_max;
     long long bytes;
 };
@@ -149,6 +157,12 @@ Ws carve(void* base, long long K, long long ldU, long long capV) {
     w.alpha_trial = (double*)take(K * 8);
     w.g_trial = (double*)take(K * 8);
     w.d_trial = (double*)take(K * 8);
+    w.ctrl2 = (Ctrl*)take(sizeof(Ctrl));
+    w.part2 = (Partial*)take(w.nseg_max * (long long)sizeof(Partial));
+    w.alpha_cur2 = (double*)take(K * 8);
+    w.g_cur2 = (double*)take(K * 8);
+    w.d_cur2 = (double*)take(K * 8);
+    w.alpha_trial2 = (double*)take(K * 8);
     w.bytes = off;
     return w;
 }
@@ -545,13 +559,20 @@ __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
 }
 
 // Segment table of the statistics (build_segments) and the start state of the loop, one launch.
+// init_acc != NULL: the start point is the CLI's (DE/fdp.py:104-108) computed here from the mean
+// accumulators, with dme_cli_init_alphas' own arithmetic (same bits), instead of being read from
+// `alpha`.  status != NULL: the statistics pass's status words ride along in result[8..16), so one
+// device-to-host copy at the end brings the solver's verdict and the data-error counters.
 __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* alpha, long long K,
                                                            long long phase, const long long* lenU,
                                                            const long long* lenV, long long ldU,
-                                                           long long capV, long long* result) {
+                                                           long long capV, long long* result,
+                                                           const double* init_acc, const u64* status) {
+    static_assert(STEP_BLOCK == 512, "dme_cli_init_alphas sums with 512 threads too");
     __shared__ BlockShared sh;
     const int tid = threadIdx.x;
     if (result && tid < 8) result[tid] = 0;  // [6] is the done word the host polls
+    if (result && status && tid < 8) result[8 + tid] = (long long)status[tid];
     build_segments(w.ctrl, lenU, lenV, K, ldU, capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
     if (tid == 0) {
         Ctrl* c = w.ctrl;
@@ -559,7 +580,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
         c->error = 0; c->launches = 0; c->branch = 0; c->currentLoss = 0.0; c->learnRate = 1.0;
         c->hconst_cur = 0.0; c->fragile = 0;
     }
-    for (long long k = tid; k < K; k += STEP_BLOCK) w.alpha_trial[k] = alpha[k];
+    if (init_acc) {
+        const double priorSum = dme_cli_prior_sum<STEP_BLOCK>(init_acc, K, sh.dbl);
+        for (long long k = tid; k < K; k += STEP_BLOCK)
+            w.alpha_trial[k] = __dadd_rn(__ddiv_rn(init_acc[k], priorSum), 0.01);
+    } else {
+        for (long long k = tid; k < K; k += STEP_BLOCK) w.alpha_trial[k] = alpha[k];
+    }
     __syncthreads();
     finish_trial(w.ctrl, w.alpha_trial, K, sh);
 }
@@ -571,7 +598,10 @@ template <bool CPT>
 __device__ void step_body(const Ws& w, long long K, long long iterations, const Prior& pr,
                           double* trace, double* trace_alpha, long long trace_cap,
                           double* alpha_out, long long* result, double* final_loss,
-                          BlockShared& sh) {
+                          BlockShared& sh, const bool writer = true) {
+    // `writer`: this workgroup publishes the outputs (alpha_out, result, final_loss, the trace).  In
+    // iter_kernel every workgroup runs this function redundantly on its own LDS copy of the state and
+    // only workgroup 0 writes.
     Ctrl* c = w.ctrl;
     if (c->done) return;
     const int tid = threadIdx.x;
@@ -603,10 +633,13 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
 
     auto finish = [&](long long reason, long long err) {
         // returned priors are alpha_cur
-        for (long long k = tid; k < K; k += STEP_BLOCK) alpha_out[k] = w.alpha_cur[k];
+        if (writer)
+            for (long long k = tid; k < K; k += STEP_BLOCK) alpha_out[k] = w.alpha_cur[k];
         if (tid == 0) {
             c->done = 1; c->exit_reason = reason; c->error = err; c->count = count;
             c->n_evals = n_evals; c->currentLoss = currentLoss;
+        }
+        if (tid == 0 && writer) {
             result[0] = reason; result[1] = count; result[2] = n_evals; result[3] = err;
             result[6] = 1;  // done: what the host polls
             result[4] = c->launches + 1;
@@ -714,7 +747,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
     }
     count += 1;
     const double gradSq = G.gradSq;  // :142 — an accepted point is always an evaluated one
-    if (count - 1 < trace_cap) {
+    if (count - 1 < trace_cap && writer) {
         if (trace && tid == 0) {
             double* t = trace + (count - 1) * 4;
             t[0] = currentLoss; t[1] = gradSq; t[2] = (double)branch; t[3] = learnRate;
@@ -789,6 +822,90 @@ __global__ __launch_bounds__(STEP_BLOCK) void small_solve_kernel(Ws w, EvalArgs 
             break;
         }
     }
+}
+
+// Mid-size problems (K up to FUSED_KMAX columns, more segments than one workgroup evaluates well):
+// ONE launch per evaluation instead of an (eval, step) pair.  Launch j first consumes the partial
+// sums of evaluation j - 1: EVERY workgroup runs the same step_body redundantly on its own LDS copy
+// of the state (control block + the six K-vectors), so every workgroup knows the next trial point
+// without any hand-off inside the launch; then the workgroups share out the segments of that
+// point's evaluation.  Only workgroup 0 writes the state and the outputs, into the copy the next
+// launch reads (two copies, alternating: no workgroup reads what another one writes in the same
+// launch).  Same device functions, same order of operations as the pair chain: the same bits
+// (test_single_launch_and_chained_solvers_agree_bit_for_bit).  Each launch saved is ~4.5 us of the
+// solver's critical path (profiles/r2_notes.md).
+constexpr long long FUSED_KMAX = 2048;  // 6 K-vectors in LDS: 96 KiB
+
+template <bool CPT>
+__global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, long long K,
+                                                          long long iterations, Prior pr,
+                                                          double* trace, double* trace_alpha,
+                                                          long long trace_cap, double* alpha_out,
+                                                          long long* result, double* final_loss,
+                                                          int parity, int first) {
+    extern __shared__ __attribute__((aligned(16))) double kvec[];  // [6][K]
+    __shared__ BlockShared sh;
+    __shared__ Ctrl lc;
+    const int tid = threadIdx.x;
+    const Ctrl* cin = parity ? w.ctrl2 : w.ctrl;
+    Ctrl* cout = parity ? w.ctrl : w.ctrl2;
+    if (cin->done) {  // uniform over the grid: the solve ended in an earlier launch
+        if (blockIdx.x == 0 && tid == 0) cout->done = 1;  // the launch after this one reads `cout`
+        return;
+    }
+    const double* in_acur = parity ? w.alpha_cur2 : w.alpha_cur;
+    const double* in_gcur = parity ? w.g_cur2 : w.g_cur;
+    const double* in_dcur = parity ? w.d_cur2 : w.d_cur;
+    const double* in_atr = parity ? w.alpha_trial2 : w.alpha_trial;
+    double* l_acur = kvec;
+    double* l_gcur = kvec + K;
+    double* l_dcur = kvec + 2 * K;
+    double* l_atr = kvec + 3 * K;
+    if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)&lc)[tid] = ((const long long*)cin)[tid];
+    for (long long k = tid; k < K; k += STEP_BLOCK) {
+        l_atr[k] = in_atr[k];
+        if (!first) {  // the first launch only evaluates the start point
+            l_acur[k] = in_acur[k];
+            l_gcur[k] = in_gcur[k];
+            l_dcur[k] = in_dcur[k];
+        }
+    }
+    __syncthreads();
+    Ws lw = w;
+    lw.ctrl = &lc;
+    lw.alpha_cur = l_acur;
+    lw.g_cur = l_gcur;
+    lw.d_cur = l_dcur;
+    lw.alpha_trial = l_atr;
+    lw.g_trial = kvec + 4 * K;
+    lw.d_trial = kvec + 5 * K;
+    lw.part = parity ? w.part2 : w.part;
+    const bool writer = blockIdx.x == 0;
+    if (!first)
+        step_body<CPT>(lw, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
+                       final_loss, sh, writer);
+    __syncthreads();
+    if (writer) {
+        if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)cout)[tid] = ((const long long*)&lc)[tid];
+        double* o_acur = parity ? w.alpha_cur : w.alpha_cur2;
+        double* o_gcur = parity ? w.g_cur : w.g_cur2;
+        double* o_dcur = parity ? w.d_cur : w.d_cur2;
+        double* o_atr = parity ? w.alpha_trial : w.alpha_trial2;
+        for (long long k = tid; k < K; k += STEP_BLOCK) {
+            o_atr[k] = l_atr[k];
+            if (!first) {
+                o_acur[k] = l_acur[k];
+                o_gcur[k] = l_gcur[k];
+                o_dcur[k] = l_dcur[k];
+            }
+        }
+    }
+    // the evaluation of the new trial point (nothing to do once done, or for a trial with an
+    // alpha <= 0, which scores inf without an evaluation: eval_segments checks both)
+    eval_segments(&lc, w.seg_k, w.seg_start, e.Uf, e.ldU, e.lenU, e.Vf, e.capV, e.lenV, K, l_atr,
+                  parity ? w.part : w.part2,
+                  (long long)blockIdx.x * STEP_WAVES + (threadIdx.x >> 6),
+                  (long long)gridDim.x * STEP_WAVES);
 }
 
 // dme_eval epilogue: publish the evaluated quantities
@@ -894,7 +1011,8 @@ int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, alpha, (long long)K,
                        (long long)PH_EVALONLY, (const long long*)lenU, (const long long*)lenV,
-                       (long long)ldU, (long long)capV, (long long*)nullptr);
+                       (long long)ldU, (long long)capV, (long long*)nullptr, (const double*)nullptr,
+                       (const u64*)nullptr);
     // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
     hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
                        w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
@@ -1013,97 +1131,187 @@ extern "C" int dme_predicted_step_alt(double hconst, const double* hdiag, const 
     return DME_OK;
 }
 
+// Launch structure of dme_solve / dme_solve_cpt for the calling host thread (include/dme_hip.h).
+static thread_local int g_solve_path = DME_SOLVE_PATH_AUTO;
+
+extern "C" int dme_solve_set_path(int path) {
+    if (path < DME_SOLVE_PATH_AUTO || path > DME_SOLVE_PATH_FUSED)
+        return dme_set_error(DME_ERR_INVALID_ARG, "unknown solver path %d", path);
+    g_solve_path = path;
+    return DME_OK;
+}
+
 namespace {
 
-int solve_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
-               const int64_t* lenV, int64_t K, double* alpha, int64_t iterations, Prior pr,
-               double* trace, double* trace_alpha, int64_t trace_cap, int64_t* result,
-               int64_t* result_host, double* final_loss, void* workspace, int64_t workspace_bytes,
-               void* stream) {
-    Ws w;
-    int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
-                          workspace, workspace_bytes, &w);
-    if (rc) return rc;
-    DME_REQUIRE(alpha && result, "null pointer");
-    DME_REQUIRE(iterations >= 0 && trace_cap >= 0, "negative iterations / trace_cap");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)alpha,
-                       (long long)K, (long long)PH_INIT, (const long long*)lenU,
-                       (const long long*)lenV, (long long)ldU, (long long)capV, (long long*)result);
-    DME_HIP_CHECK(hipGetLastError());
-    const unsigned grid = eval_grid(w.nseg_max);
-    // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
-    const long long max_pairs = (iterations + 2) * 450 + 16;
-    long long pairs = 0;
-    // Typical solves take 5-15 evaluations.  The first batch is enqueued while earlier work on the
-    // stream (the statistics pass) still runs, so its launches cost the host nothing, but a launch
-    // pair that finds the solve finished still costs ~9 us of device time and a batch that falls
-    // short costs a host round trip (~25 us).  Solves come in series on similar statistics (EM
-    // rounds, re-estimation as rows arrive, the steps of a benchmark): the first batch covers what
-    // this thread's previous solve of the same shape needed plus one pair, 16 pairs otherwise.
-    static thread_local long long hint_K = -1, hint_ldU = -1, hint_pairs = 0;
-    int batch = 16;
-    if (hint_K == K && hint_ldU == ldU && hint_pairs > 0)
-        batch = (int)(hint_pairs + 1 < 4 ? 4 : (hint_pairs + 1 > 32 ? 32 : hint_pairs + 1));
-    long long* pinned = poll_buffer();
-    if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
-    long long done = 0;
-    const bool cpt = pr.beta != nullptr || pr.has_W;
-    long long small_nseg = SMALL_NSEG;
-    if (const char* e = getenv("DME_SOLVE_SMALL_NSEG")) small_nseg = atoll(e);  // test hook: 0 = never
-    if (w.nseg_max <= small_nseg) {
-        const EvalArgs ea{Uf, (long long)ldU, (const long long*)lenU, Vf, (long long)capV,
-                          (const long long*)lenV};
-        if (cpt)
-            hipLaunchKernelGGL(small_solve_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
-                               (long long)K, (long long)iterations, pr, trace, trace_alpha,
-                               (long long)trace_cap, alpha, (long long*)result, final_loss, max_pairs);
-        else
-            hipLaunchKernelGGL(small_solve_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
-                               (long long)K, (long long)iterations, pr, trace, trace_alpha,
-                               (long long)trace_cap, alpha, (long long*)result, final_loss, max_pairs);
+// Everything a solve needs besides the workspace: the arguments of dme_solve / dme_solve_enqueue.
+struct SolveCall {
+    const double* Uf;
+    long long ldU;
+    const long long* lenU;
+    const double* Vf;
+    long long capV;
+    const long long* lenV;
+    long long K;
+    double* alpha;
+    long long iterations;
+    Prior pr;
+    const double* init_acc;  // start from the CLI's initial alphas (set-up computes them), or NULL
+    const u64* status;       // statistics status words to carry into result[8..16), or NULL
+    double* trace;
+    double* trace_alpha;
+    long long trace_cap;
+    long long* result;
+    double* final_loss;
+};
+
+int pick_path(long long K, long long nseg_max) {
+    const int forced = g_solve_path;
+    if (forced == DME_SOLVE_PATH_SINGLE || (forced == DME_SOLVE_PATH_AUTO && nseg_max <= SMALL_NSEG))
+        return DME_SOLVE_PATH_SINGLE;
+    if (K <= FUSED_KMAX && (forced == DME_SOLVE_PATH_FUSED || forced == DME_SOLVE_PATH_AUTO))
+        return DME_SOLVE_PATH_FUSED;
+    return DME_SOLVE_PATH_CHAIN;
+}
+
+// every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
+long long max_launches(long long iterations) { return (iterations + 2) * 450 + 16; }
+
+// Enqueues launches [first, first + count) of a solve on `s` (launch 0 is preceded by the set-up
+// kernel).  What one launch is depends on the structure: FUSED - one iter_kernel (the first only
+// evaluates the start point, so n evaluations take n + 1 launches); CHAIN - an (eval, step) pair;
+// SINGLE - the whole loop (first == 0 only; count is ignored).  Nothing is waited for.
+int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first, long long count,
+                     hipStream_t s) {
+    const bool cpt = c.pr.beta != nullptr || c.pr.has_W;
+    const EvalArgs ea{c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV};
+    if (first == 0) {
+        hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)c.alpha,
+                           c.K, (long long)PH_INIT, c.lenU, c.lenV, c.ldU, c.capV, c.result,
+                           c.init_acc, c.status);
         DME_HIP_CHECK(hipGetLastError());
-        DME_HIP_CHECK(hipMemcpyAsync(pinned, result, 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
-        DME_HIP_CHECK(hipStreamSynchronize(s));
-        done = 1;
     }
-    while (!done) {
-        for (int i = 0; i < batch; ++i) {
+    if (path == DME_SOLVE_PATH_SINGLE) {
+        if (first != 0) return DME_OK;
+        const long long rounds = max_launches(c.iterations);
+        if (cpt)
+            hipLaunchKernelGGL(small_solve_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea, c.K,
+                               c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
+                               c.result, c.final_loss, rounds);
+        else
+            hipLaunchKernelGGL(small_solve_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea, c.K,
+                               c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
+                               c.result, c.final_loss, rounds);
+    } else if (path == DME_SOLVE_PATH_FUSED) {
+        const size_t lds = (size_t)(6 * c.K * 8);
+        int dev = 0;
+        DME_HIP_CHECK(hipGetDevice(&dev));
+        static bool attr_set[2][64] = {};
+        if (dev < 0 || dev >= 64 || !attr_set[cpt ? 1 : 0][dev]) {
+            const void* fn = cpt ? (const void*)iter_kernel<true> : (const void*)iter_kernel<false>;
+            DME_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(6 * FUSED_KMAX * 8)));
+            if (dev >= 0 && dev < 64) attr_set[cpt ? 1 : 0][dev] = true;
+        }
+        // one wave per segment and round; every workgroup repeats the step, so no more of them than
+        // the evaluation can use
+        int cus = dme_device_cus();
+        if (cus <= 0) cus = 256;
+        long long fg = (w.nseg_max + STEP_WAVES - 1) / STEP_WAVES;
+        if (fg > cus) fg = cus;
+        if (fg < 1) fg = 1;
+        for (long long j = first; j < first + count; ++j) {
+            const int parity = (int)(j & 1), is_first = j == 0 ? 1 : 0;
+            if (cpt)
+                hipLaunchKernelGGL(iter_kernel<true>, dim3((unsigned)fg), dim3(STEP_BLOCK), lds, s, w,
+                                   ea, c.K, c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap,
+                                   c.alpha, c.result, c.final_loss, parity, is_first);
+            else
+                hipLaunchKernelGGL(iter_kernel<false>, dim3((unsigned)fg), dim3(STEP_BLOCK), lds, s, w,
+                                   ea, c.K, c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap,
+                                   c.alpha, c.result, c.final_loss, parity, is_first);
+        }
+    } else {
+        const unsigned grid = eval_grid(w.nseg_max);
+        for (long long j = first; j < first + count; ++j) {
             hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, w.ctrl, w.seg_k,
-                               w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
-                               (long long)capV, (const long long*)lenV, (long long)K,
+                               w.seg_start, c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K,
                                w.alpha_trial, w.part);
             if (cpt)
-                hipLaunchKernelGGL(step_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
-                                   (long long)K, (long long)iterations, pr, trace, trace_alpha,
-                                   (long long)trace_cap, alpha, (long long*)result, final_loss);
+                hipLaunchKernelGGL(step_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, c.K,
+                                   c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
+                                   c.result, c.final_loss);
             else
-                hipLaunchKernelGGL(step_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
-                                   (long long)K, (long long)iterations, pr, trace, trace_alpha,
-                                   (long long)trace_cap, alpha, (long long*)result, final_loss);
+                hipLaunchKernelGGL(step_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, c.K,
+                                   c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
+                                   c.result, c.final_loss);
         }
-        pairs += batch;
-        DME_HIP_CHECK(hipGetLastError());
-        // one 64-byte copy brings the done flag (first word of Ctrl is not it: result[] is) ...
-        DME_HIP_CHECK(hipMemcpyAsync(pinned, result, 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
-        DME_HIP_CHECK(hipStreamSynchronize(s));
-        done = pinned[6];
-        if (!done && pairs > max_pairs)
-            return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld evaluations", pairs);
-        batch = pairs < 64 ? 8 : 32;
     }
-    const long long* res = pinned;  // the last poll already brought the whole result block
-    hint_K = K;
-    hint_ldU = ldU;
-    hint_pairs = res[4];  // launch pairs that did work
-    if (result_host)
-        for (int i = 0; i < 8; ++i) result_host[i] = res[i];
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+// Solves come in series on similar statistics (EM rounds, re-estimation as rows arrive, the steps of a
+// benchmark).  The first batch is enqueued while earlier work on the stream (the statistics pass)
+// still runs, so its launches cost the host nothing, but a launch that finds the solve finished still
+// costs ~5 us of device time and a batch that falls short a host round trip (~25 us): the first batch
+// covers what this thread's previous solve of the same shape needed plus one spare, 16 evaluations
+// otherwise.
+thread_local long long hint_K = -1, hint_ldU = -1, hint_launches = 0;
+
+long long first_batch(long long K, long long ldU, int path) {
+    long long evals = 16;
+    if (hint_K == K && hint_ldU == ldU && hint_launches > 0) {
+        evals = hint_launches + 1;
+        if (evals < 4) evals = 4;
+        if (evals > 32) evals = 32;
+    }
+    return path == DME_SOLVE_PATH_FUSED ? evals + 1 : evals;  // FUSED: the first launch only evaluates
+}
+
+int check_call(const SolveCall& c) {
+    DME_REQUIRE(c.alpha && c.result, "null pointer");
+    DME_REQUIRE(c.iterations >= 0 && c.trace_cap >= 0, "negative iterations / trace_cap");
+    return DME_OK;
+}
+
+int result_error(const long long* res) {
     if (res[3] == DME_ERR_ZERO_DIVISION)
         return dme_set_error(DME_ERR_ZERO_DIVISION, "float division by zero (an all-zero column or empty V)");
     if (res[3] == DME_ERR_MATH_DOMAIN)
         return dme_set_error(DME_ERR_MATH_DOMAIN, "math domain error (non-positive initial alpha)");
     if (res[3] != 0) return dme_set_error(DME_ERR_INTERNAL, "solver error %lld", res[3]);
     return DME_OK;
+}
+
+int solve_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_t workspace_bytes,
+               void* stream) {
+    Ws w;
+    int rc = check_common(c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K, workspace, workspace_bytes, &w);
+    if (rc) return rc;
+    if ((rc = check_call(c))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int path = pick_path(c.K, w.nseg_max);
+    const long long limit = max_launches(c.iterations);
+    long long* pinned = poll_buffer();
+    if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
+    long long launched = 0, batch = first_batch(c.K, c.ldU, path), done = 0;
+    while (!done) {
+        if ((rc = enqueue_launches(c, w, path, launched, batch, s))) return rc;
+        launched += batch;
+        // one 64-byte copy brings the done flag and, once it is set, the whole result block
+        DME_HIP_CHECK(hipMemcpyAsync(pinned, c.result, 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
+        DME_HIP_CHECK(hipStreamSynchronize(s));
+        done = pinned[6];
+        if (!done && (launched > limit || path == DME_SOLVE_PATH_SINGLE))
+            return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", launched);
+        batch = launched < 64 ? 8 : 32;
+    }
+    hint_K = c.K;
+    hint_ldU = c.ldU;
+    hint_launches = pinned[4];  // evaluations' worth of launches that did work
+    if (result_host)
+        for (int i = 0; i < 8; ++i) result_host[i] = pinned[i];
+    return result_error(pinned);
 }
 
 }  // namespace
@@ -1114,9 +1322,10 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
                          int64_t trace_cap, int64_t* result, int64_t* result_host,
                          double* final_loss, void* workspace, int64_t workspace_bytes,
                          void* stream) {
-    const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
-    return solve_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, iterations, pr, trace, trace_alpha,
-                      trace_cap, result, result_host, final_loss, workspace, workspace_bytes, stream);
+    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
+                      iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, nullptr, nullptr, trace,
+                      trace_alpha, trace_cap, (long long*)result, final_loss};
+    return solve_impl(c, result_host, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dme_solve_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
@@ -1126,7 +1335,43 @@ extern "C" int dme_solve_cpt(const double* Uf, int64_t ldU, const int64_t* lenU,
                              int64_t* result_host, double* final_loss, void* workspace,
                              int64_t workspace_bytes, void* stream) {
     // inside findDirichletPriors the loss carries no prior term (CPT/dme.py:109-110)
-    const Prior pr{0.0, beta, W, has_W ? 1 : 0, 1};
-    return solve_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, iterations, pr, trace, trace_alpha,
-                      trace_cap, result, result_host, final_loss, workspace, workspace_bytes, stream);
+    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
+                      iterations, Prior{0.0, beta, W, has_W ? 1 : 0, 1}, nullptr, nullptr, trace,
+                      trace_alpha, trace_cap, (long long*)result, final_loss};
+    return solve_impl(c, result_host, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                                 int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                                 int64_t iterations, double hyperprior, const double* init_acc,
+                                 const uint64_t* status, double* trace, double* trace_alpha,
+                                 int64_t trace_cap, int64_t* result, int64_t* result_host,
+                                 void* workspace, int64_t workspace_bytes, int64_t first,
+                                 int64_t count, int64_t* enqueued, void* stream) {
+    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
+                      iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, init_acc, (const u64*)status,
+                      trace, trace_alpha, trace_cap, (long long*)result, nullptr};
+    Ws w;
+    int rc = check_common(c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K, workspace, workspace_bytes, &w);
+    if (rc) return rc;
+    if ((rc = check_call(c))) return rc;
+    DME_REQUIRE(first >= 0 && count >= 0 && result_host && enqueued, "bad first / count / null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int path = pick_path(K, w.nseg_max);
+    if (first > max_launches(iterations))
+        return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", (long long)first);
+    if (count == 0) count = first == 0 ? first_batch(K, ldU, path) : (first < 64 ? 8 : 32);
+    if ((rc = enqueue_launches(c, w, path, first, count, s))) return rc;
+    *enqueued = count;
+    DME_HIP_CHECK(hipMemcpyAsync(result_host, result, 16 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    return DME_OK;
+}
+
+extern "C" int dme_solve_finish(const int64_t* result_host, int64_t K, int64_t ldU) {
+    DME_REQUIRE(result_host != nullptr, "null pointer");
+    if (!result_host[6]) return DME_OK;  // not done: the caller enqueues more launches
+    hint_K = K;
+    hint_ldU = ldU;
+    hint_launches = result_host[4];
+    return result_error((const long long*)result_host);
 }

@@ -20,6 +20,8 @@ import torch
 
 from . import _lib
 
+TRACE_CAP = 4096  # iterations whose trace (loss, gradient size, branch, alphas) is kept
+
 EXIT_MESSAGES = {
     1: "Converged with small gradient",    # DE/dme.py:146
     2: "Converged with small learn rate",  # DE/dme.py:183
@@ -184,7 +186,9 @@ class DeviceUV:
                 a = torch.as_tensor(np.array(init_alphas, dtype=np.float64)).to(self.device)
             if a.numel() != self.K:
                 raise ValueError(f"expected {self.K} alphas, got {a.numel()}")
-            cap = max(iterations, 1)
+            # the trace holds the first TRACE_CAP iterations (the reference's cost depends on the
+            # iterations actually run, typically ~10; `-i 1000000` must not allocate gigabytes)
+            cap = min(max(iterations, 1), TRACE_CAP)
             # one buffer: result[8] int64 | final loss | trace[cap][4]   (+ optional alphas trace)
             buf = torch.empty(8 + 1 + cap * 4, dtype=torch.float64, device=self.device)
             result = buf[:8].view(torch.int64)
@@ -223,8 +227,8 @@ class SolveResult(dict):
         super().__init__()
         self._lazy = {
             "alpha": lambda: alpha_dev.cpu().numpy(),
-            "trace": lambda: trace_dev[:res[1]].cpu().numpy(),
-            "trace_alpha": (lambda: talpha_dev.view(cap, K)[:res[1]].cpu().numpy())
+            "trace": lambda: trace_dev[:min(res[1], cap)].cpu().numpy(),
+            "trace_alpha": (lambda: talpha_dev.view(cap, K)[:min(res[1], cap)].cpu().numpy())
             if talpha_dev is not None else (lambda: None),
         }
         dict.update(self, {
@@ -433,6 +437,10 @@ class DeviceStats:
             st = self._pinned.numpy().copy()
         else:
             st = self.status.cpu().numpy()
+        return self._verdict(st)
+
+    def _verdict(self, st):
+        """The status words of the statistics pass as exceptions / the rows-and-maxima record."""
         if st[6]:
             raise ValueError("CSR input inconsistent: rowptr is negative, decreasing, or spans more "
                              "entries than colidx / vals hold")
@@ -533,6 +541,15 @@ class DeviceStats:
                 ldU, _ptr(lenU), _ptr(V), _ptr(Vf), _ptr(lenV), _stream()))
         return DeviceUV(K, Uf, ldU, lenU, Vf, lenV, U=U, V=V)
 
+    def estimate_async(self, iterations, hyperprior=0.0):
+        """The CLI's tail (DE/fdp.py:104-113) enqueued in one go, without waiting: suffix scan, initial
+        alphas from the mean accumulators, the Newton loop (dme_suffix_scan + dme_solve_enqueue).
+        Returns a PendingEstimate; its result() waits, raises what check() / solve() would raise and
+        returns the solver's record plus `info` (rows, maxima).  The host is free to enqueue the next
+        job's statistics pass meanwhile, so the GPU does not idle between jobs."""
+        uv = self.finalize()
+        return PendingEstimate(self, uv, int(iterations), float(hyperprior))
+
     def cli_init_alphas(self):
         """DE/fdp.py:104-108 on the device: init_acc / (sum + 0.01) + 0.01."""
         with _on(self.device):
@@ -540,6 +557,56 @@ class DeviceStats:
             _lib.check(_lib.lib().dme_cli_init_alphas(_ptr(self.init_acc), self.K, _ptr(a0),
                                                       _stream()))
         return a0
+
+
+class PendingEstimate:
+    """A solve that has been enqueued (DeviceStats.estimate_async)."""
+
+    def __init__(self, stats, uv, iterations, hyperprior):
+        self.stats, self.uv = stats, uv
+        self.iterations, self.hyperprior = iterations, hyperprior
+        dev, K = stats.device, stats.K
+        with _on(dev):
+            self.alpha = torch.empty(K, dtype=torch.float64, device=dev)
+            self.cap = min(max(iterations, 1), TRACE_CAP)
+            # result[16] int64 | trace[cap][4]
+            self.buf = torch.empty(16 + self.cap * 4, dtype=torch.float64, device=dev)
+            self.host = torch.zeros(16, dtype=torch.int64, pin_memory=True)
+            self.stream = torch.cuda.current_stream()
+            self.launched = 0
+            self._done = None
+            self._enqueue()
+
+    def _enqueue(self):
+        uv, st = self.uv, self.stats
+        ws, wsb = uv.workspace()
+        n = ctypes.c_int64(0)
+        _lib.check(_lib.lib().dme_solve_enqueue(
+            _ptr(uv.Uf), uv.ldU, _ptr(uv.lenU), _ptr(uv.Vf), uv.capV, _ptr(uv.lenV), uv.K,
+            _ptr(self.alpha), self.iterations, self.hyperprior, _ptr(st.init_acc), _ptr(st.status),
+            self.buf.data_ptr() + 16 * 8, 0, self.cap, self.buf.data_ptr(), self.host.data_ptr(),
+            ws, wsb, self.launched, 0, ctypes.addressof(n), self.stream.cuda_stream))
+        self.launched += n.value
+
+    def result(self):
+        if self._done is not None:
+            return self._done
+        with _on(self.stats.device):
+            while True:
+                self.stream.synchronize()
+                if int(self.host[6]):
+                    break
+                self._enqueue()  # the default batch fell short: more launches, another wait
+            res = self.host.tolist()
+            _lib.check(_lib.lib().dme_solve_finish(self.host.data_ptr(), self.uv.K, self.uv.ldU))
+            info = self.stats._verdict(res[8:16])
+            out = SolveResult(self.alpha, res[:8], self.buf[16:].view(self.cap, 4), None, self.cap,
+                              self.uv.K)
+            out["info"] = info
+            out["uv"] = self.uv
+            out["stats"] = self.stats
+        self._done = out
+        return out
 
 
 class WeightedStats:

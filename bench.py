@@ -66,6 +66,9 @@ def parse():
                     help="untimed statistics passes before the warm-up steps (see main)")
     ap.add_argument("--phase-steps", type=int, default=5,
                     help="extra untimed steps that carry the per-phase events")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="wait on the host after every timed step instead of enqueueing the steps "
+                         "back to back (the headline then equals `sync_ms_per_step`)")
     ap.add_argument("--verify", action="store_true",
                     help="check size-independent properties of the statistics after the run")
     return ap.parse_args()
@@ -147,7 +150,10 @@ def main():
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
-    def one_step(timers=None, phases=None):
+    def one_step(timers=None, phases=None, wait=True):
+        """One pass of the hot path.  wait=False returns the enqueued job (a PendingEstimate): the
+        host goes on to enqueue the next step while the GPU works, and the results are collected -
+        and checked - before the clock stops."""
         st = dev.DeviceStats(K, M, M, device=device)
         if timers is not None or phases is not None:
             e0, e1 = ev(), ev()
@@ -160,19 +166,18 @@ def main():
         if phases is not None:
             e2 = ev()
             e2.record()
-        uv = st.finalize()
-        a0 = st.cli_init_alphas()
-        st.check_async()  # status words travel to pinned memory behind the scan
-        out = uv.solve(a0, args.iterations, 0.0, trace_alphas=False, consume_init=True)  # synchronises
-        info = st.check()
+        pend = st.estimate_async(args.iterations, 0.0)  # scan + CLI initial alphas + Newton loop
+        if timers is not None:
+            timers.append((e0, e1))
+        if not wait:
+            return pend
+        out = pend.result()  # synchronises; raises on data errors / solver errors
         if phases is not None:
             e3 = ev()
             e3.record()
             e3.synchronize()
             phases.append((e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)))
-        if timers is not None:
-            timers.append((e0, e1))
-        return st, uv, out, info
+        return out
 
     # initialisation that is not a step: code objects are loaded and, with several ranks, the RCCL
     # communicator is created (a tiny collective), so that even --warmup 0 times steady-state steps
@@ -204,23 +209,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    timers = []
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        st, uv, out, info = one_step(timers)
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.cpu()[0])
+    def timed(pipelined):
+        timers, outs = [], []
+        barrier()
+        t_start = time.perf_counter()
+        if pipelined:
+            pends = [one_step(timers, wait=False) for _ in range(args.steps)]
+            barrier()
+            outs = [p.result() for p in pends]  # host reads of pinned words: every job is checked
+        else:
+            outs = [one_step(timers) for _ in range(args.steps)]
+            barrier()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.cpu()[0])
+        for o in outs:
+            # proof that the collective saw every rank: the reduced statistics count the job's rows
+            assert o["info"]["rows"] == total_rows, (o["info"], total_rows)
+            assert o["exit"] in (1, 2, 3)
+        return elapsed, timers, outs
+
+    # the K timed steps: enqueued back to back (no host wait between steps), synchronised and checked
+    # before the clock stops; then, outside the headline, the same K steps with a host wait after each
+    elapsed, timers, outs = timed(pipelined=not args.sync_steps)
+    out = outs[-1]
+    uv = out["uv"]
+    uv_stats = outs[-1].get("stats")
+    sync_elapsed = elapsed if args.sync_steps else timed(pipelined=False)[0]
 
     ms_per_step = elapsed / args.steps * 1e3
     stats_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))
     value = total_rows / (elapsed / args.steps)
-    # proof that the collective saw every rank: the reduced statistics count the whole job's rows
-    assert info["rows"] == total_rows, (info, total_rows)
 
     # per-phase times from extra steps outside the timed region (an event costs device time)
     phases = []
@@ -276,6 +297,10 @@ def main():
             "stats": stats_ms,
             "rest (all-reduce + scan + init + solve + check + host)": ms_per_step - stats_ms,
         },
+        "step_issue": ("a host wait after every step" if args.sync_steps else
+                       "the K steps are enqueued back to back on one stream; one synchronise, then "
+                       "every job's result is checked, before the clock stops"),
+        "sync_ms_per_step": sync_elapsed / args.steps * 1e3,
         "solver": {"iterations": out["n_iters"], "loss_evals": out["n_evals"], "exit": out["exit"],
                    "launches": out["launches"], "final_loss": out["final_loss"],
                    "fragile_decisions": out["fragile_decisions"]},
@@ -311,7 +336,7 @@ def main():
         # the solver's cost does not depend on N: time it on the full-size statistics
         Ufull, Vfull = uv.to_lists()
         full = oracle.stats_from_lists(Ufull, Vfull)
-        a0 = st.cli_init_alphas().cpu().numpy()
+        a0 = uv_stats.cli_init_alphas().cpu().numpy()
         t0 = time.perf_counter()
         sol = oracle.find_priors(full, a0, args.iterations, 0.0)
         t_solve_cpu = time.perf_counter() - t0

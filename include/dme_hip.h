@@ -269,6 +269,47 @@ int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
               int64_t* result, int64_t* result_host, double* final_loss, void* workspace,
               int64_t workspace_bytes, void* stream);
 
+/* dme_solve without the wait, for callers that keep the GPU fed (the next job's statistics pass is
+ * enqueued while this solve still runs; the reference, one thread, has no counterpart).
+ * dme_solve_enqueue puts launches [first, first + count) of the solve on `stream` - launch 0 is
+ * preceded by the set-up - followed by a copy of result[16] to result_host (pinned host memory,
+ * valid once the stream has reached it), and returns at once.  count == 0 asks for the default batch
+ * (what this thread's previous solve of the same shape needed plus one spare launch; a launch that
+ * finds the solve finished ends at once); *enqueued returns the number taken.  The caller later
+ * synchronises the stream (or an event), reads result_host[6] (done) and, if it is 0, calls again with
+ * first = the launches enqueued so far.  Once done, dme_solve_finish(result_host, K, ldU) maps
+ * result_host[3] to the return code of dme_solve (DME_ERR_ZERO_DIVISION, ...) and records the launch
+ * count for the next default batch.
+ *   init_acc [dev][K] or NULL: start from the CLI's initial alphas computed from the mean
+ *       accumulators (DE/fdp.py:104-108, the bits of dme_cli_init_alphas) instead of reading them
+ *       from `alpha`, which is then output only;
+ *   status [dev][8] or NULL: the statistics pass's status words, copied into result[8..16) so that
+ *       the one host copy also brings the data-error counters;
+ *   result [dev][16], result_host [host][16]: words 0..7 as for dme_solve. */
+int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
+                      int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                      int64_t iterations, double hyperprior, const double* init_acc,
+                      const uint64_t* status, double* trace, double* trace_alpha, int64_t trace_cap,
+                      int64_t* result /*[dev][16]*/, int64_t* result_host /*[host][16]*/,
+                      void* workspace, int64_t workspace_bytes, int64_t first, int64_t count,
+                      int64_t* enqueued /*[host][1] out*/, void* stream);
+int dme_solve_finish(const int64_t* result_host /*[host][16]*/, int64_t K, int64_t ldU);
+
+/* Launch structure of dme_solve / dme_solve_cpt, for the calling host thread.  The three structures
+ * run the same device functions in the same order and return the same bits; the choice is by size:
+ *   SINGLE  at most 64 segments of 256 terms (the reference's sample files, K = 2): the whole loop
+ *           in one launch of one workgroup;
+ *   FUSED   K <= 2048: one launch per evaluation (every workgroup repeats the O(K) step on an LDS
+ *           copy of the state, then the workgroups share the evaluation of the new point);
+ *   CHAIN   otherwise: an (evaluate, step) launch pair per evaluation.
+ * DME_SOLVE_PATH_AUTO (the default) picks by size; the others pin a structure (FUSED falls back to
+ * CHAIN beyond K = 2048) - for tests and timing comparisons.  No reference counterpart. */
+#define DME_SOLVE_PATH_AUTO 0
+#define DME_SOLVE_PATH_CHAIN 1
+#define DME_SOLVE_PATH_SINGLE 2
+#define DME_SOLVE_PATH_FUSED 3
+int dme_solve_set_path(int path);
+
 /* The same two entries with the (Beta, W) conjugate hyperprior of
  * ConjugatePriorTools/dirichletMultinomialEstimation.py ("CPT/dme.py") instead of the scalar one:
  *   beta [dev][K] or NULL, W used when has_W != 0.

@@ -131,25 +131,110 @@ def test_zero_iterations_returns_init():
     assert out["alpha"].tolist() == [0.5, 0.25]
 
 
-def test_single_launch_and_chained_solvers_agree_bit_for_bit(monkeypatch):
-    """Small problems run the whole loop in one launch, larger ones as a chain of eval / step
-    launches: same device functions, same order of operations, so the same bits - checked on every
-    golden solve small enough for the single launch, all branches and exits included."""
-    from bayespy_amd import device
+def test_single_launch_and_chained_solvers_agree_bit_for_bit():
+    """The three launch structures of the solver - the whole loop in one launch (small problems), one
+    launch per evaluation with the step repeated by every workgroup (K <= 2048), an (evaluate, step)
+    launch pair per evaluation - run the same device functions in the same order of operations, so
+    they return the same bits: checked on every golden solve, all branches and exits included."""
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    CHAIN, SINGLE, FUSED = 1, 2, 3
     n = 0
-    for name in GOLDEN_CASES:
-        fx = load_golden(name)
-        uv = _uv(fx)
-        for s in fx["solves"]:
-            if s["variant"] != "DE" or "raises" in s:
-                continue
-            monkeypatch.setenv("DME_SOLVE_SMALL_NSEG", "1000000")
-            a = uv.solve(s["init"], s["iterations"], s["hyperprior"])
-            monkeypatch.setenv("DME_SOLVE_SMALL_NSEG", "0")
-            b = uv.solve(s["init"], s["iterations"], s["hyperprior"])
-            assert a["exit"] == b["exit"] and a["n_iters"] == b["n_iters"] and a["n_evals"] == b["n_evals"]
-            assert np.array_equal(a["alpha"], b["alpha"]), (name, s["init_name"])
-            assert np.array_equal(a["trace"], b["trace"])
-            assert a["final_loss"] == b["final_loss"]
-            n += 1
+    try:
+        for name in GOLDEN_CASES:
+            fx = load_golden(name)
+            uv = _uv(fx)
+            for s in fx["solves"]:
+                if s["variant"] != "DE" or "raises" in s:
+                    continue
+                outs = []
+                for path in (SINGLE, CHAIN, FUSED):
+                    if path == SINGLE and fx["K"] > 100:
+                        continue  # one workgroup for everything: minutes on the K = 1000 fixture
+                    _lib.check(L.dme_solve_set_path(path))
+                    outs.append(uv.solve(s["init"], s["iterations"], s["hyperprior"]))
+                a = outs[0]
+                for b in outs[1:]:
+                    assert a["exit"] == b["exit"] and a["n_iters"] == b["n_iters"] and a["n_evals"] == b["n_evals"]
+                    assert np.array_equal(a["alpha"], b["alpha"]), (name, s["init_name"])
+                    assert np.array_equal(a["trace"], b["trace"])
+                    assert np.array_equal(a["trace_alpha"], b["trace_alpha"])
+                    assert a["final_loss"] == b["final_loss"]
+                    assert a["fragile_decisions"] == b["fragile_decisions"]
+                n += 1
+    finally:
+        _lib.check(L.dme_solve_set_path(0))
     assert n >= 10
+    assert L.dme_solve_set_path(9) == _lib.ERR_INVALID_ARG
+
+
+def test_fused_path_raises_like_the_chain():
+    """Errors travel the same way on the one-launch-per-evaluation path: an all-zero column is a
+    ZeroDivisionError, a non-positive start a ValueError."""
+    from bayespy_amd import _lib
+    L = _lib.lib()
+    fx = load_golden("zero_column")
+    uv = _uv(fx)
+    try:
+        _lib.check(L.dme_solve_set_path(3))
+        for s in fx["solves"]:
+            if s["variant"] == "DE" and "raises" in s:
+                with pytest.raises(ZeroDivisionError):
+                    uv.solve(s["init"], s["iterations"], s["hyperprior"])
+        with pytest.raises(ValueError):
+            uv.solve([0.0] + [1.0] * (fx["K"] - 1), 50, 0.0)
+    finally:
+        _lib.check(L.dme_solve_set_path(0))
+
+
+def test_enqueued_estimate_equals_the_blocking_calls():
+    """DeviceStats.estimate_async (dme_solve_enqueue: set-up computes the CLI's initial alphas from
+    the mean accumulators, the status words ride in the result block, nobody waits) against the
+    blocking sequence finalize / cli_init_alphas / solve / check: the same bits.  Several jobs are
+    in flight at once, and one whose default batch of launches falls short continues."""
+    from bayespy_amd import device
+    fx = load_golden("dirmult_k1000")
+    X = torch.from_numpy(fx["X"].astype(np.int32)).cuda()
+    pends = []
+    for _ in range(3):
+        st = device.DeviceStats(fx["K"])
+        st.add_dense(X)
+        pends.append(st.estimate_async(50, 0.0))
+    ref_st = device.DeviceStats(fx["K"])
+    ref_st.add_dense(X)
+    info = ref_st.check()
+    ref = ref_st.finalize().solve(ref_st.cli_init_alphas(), 50, 0.0)
+    for p in pends:
+        out = p.result()
+        assert out["info"] == info
+        assert out["exit"] == ref["exit"] and out["n_iters"] == ref["n_iters"] and out["n_evals"] == ref["n_evals"]
+        assert np.array_equal(out["alpha"], ref["alpha"])
+        assert out["final_loss"] == ref["final_loss"]
+        assert np.array_equal(out["trace"], ref["trace"])
+    # a bad start (init_acc of a matrix whose counts sit in one column is fine; force many evaluations
+    # instead through a tiny first batch): continue after the first wait
+    st = device.DeviceStats(fx["K"])
+    st.add_dense(X)
+    p = device.PendingEstimate.__new__(device.PendingEstimate)
+    uv = st.finalize()
+    device.PendingEstimate.__init__(p, st, uv, 50, 0.0)
+    assert p.launched >= 2
+    out = p.result()
+    assert np.array_equal(out["alpha"], ref["alpha"])
+
+
+def test_enqueued_estimate_reports_data_errors():
+    from bayespy_amd import device
+    X = torch.tensor([[1, 2, 3], [4, 0, 600], [2, 2, 2]], dtype=torch.int32, device="cuda")
+    st = device.DeviceStats(3, 10, 20)
+    # bounds stated too small: counted as data errors by the pass, raised when the result is taken
+    rc_st = st.add_dense(X, max_count=10, max_total=20)
+    assert rc_st is st
+    with pytest.raises(ValueError, match="statistics incomplete"):
+        st.estimate_async(50, 0.0).result()
+    # an all-zero column: the reference's ZeroDivisionError
+    Z = torch.tensor([[1, 0, 3], [4, 0, 6], [2, 0, 2]], dtype=torch.int32, device="cuda")
+    st = device.DeviceStats(3)
+    st.add_dense(Z)
+    with pytest.raises(ZeroDivisionError):
+        st.estimate_async(50, 0.0).result()
