@@ -6,7 +6,8 @@
 //   sqVectorSize :104, findDirichletPriors :126-190.
 //
 // Structure.  The ragged statistics are cut into segments of SEG consecutive n of one column (the
-// row-total vector V is column K, evaluated at A = sum(alpha)).  One evaluation is
+// row-total vector V is column K, evaluated at A = sum(alpha)); a segment's slot in the partial-sum
+// table follows from its column and start (slots_per_column).  One evaluation is
 //   eval_kernel  — one wave per segment: the fp64 sums  sum U*log(a+n),  sum U/(a+n),
 //                  sum U/(a+n)^2  with compensated (two-sum) accumulation and DPP wave reductions;
 //   step_kernel  — one workgroup: gathers the per-column sums in a fixed order, forms loss,
@@ -108,10 +109,7 @@ __device__ double dme_trigamma(double x) {
 // workspace carve-up (all offsets 256-byte aligned)
 struct Ws {
     Ctrl* ctrl;
-    int* seg_k;
-    int* seg_start;
-    long long* segfirst;  // [K+2]
-    Partial* part;
+    Partial* part;  // [K * S + SV] partial sums, one slot per segment (see slots_per_column)
     double* alpha_cur;
     double* g_cur;
     double* d_cur;
@@ -126,14 +124,21 @@ struct Ws {
     double* g_cur2;
     double* d_cur2;
     double* alpha_trial2;
-    long long nseg_max;
+    long long nseg_max;  // = K * S + SV slots
     long long bytes;
 };
 
 inline long long align256(long long x) { return (x + 255) & ~255LL; }
 
-inline long long nseg_bound(long long K, long long ldU, long long capV) {
-    return K * ((ldU + SEG - 1) / SEG + 1) + (capV + SEG - 1) / SEG + 2;
+// Segments are SEG consecutive n of one column.  Column k owns the S = ceil(ldU / SEG) slots
+// [k * S, (k + 1) * S) of the partial-sum table and V (column K) the SV = ceil(capV / SEG) slots behind
+// them: a slot's column and start follow from its index and a column's slots from lenU[k] alone, so
+// neither the evaluation nor the gather chases a segment table through memory (two dependent loads
+// per launch less on the solver's critical path).  Slots beyond a column's length are never written
+// nor read.
+__host__ __device__ inline long long slots_per_column(long long ld) {
+    const long long n = (ld + SEG - 1) / SEG;
+    return n < 1 ? 1 : n;
 }
 
 Ws carve(void* base, long long K, long long ldU, long long capV) {
@@ -145,11 +150,8 @@ Ws carve(void* base, long long K, long long ldU, long long capV) {
         off += align256(bytes);
         return p;
     };
-    w.nseg_max = nseg_bound(K, ldU, capV);
+    w.nseg_max = K * slots_per_column(ldU) + slots_per_column(capV);
     w.ctrl = (Ctrl*)take(sizeof(Ctrl));
-    w.seg_k = (int*)take(w.nseg_max * 4);
-    w.seg_start = (int*)take(w.nseg_max * 4);
-    w.segfirst = (long long*)take((K + 2) * 8);
     w.part = (Partial*)take(w.nseg_max * (long long)sizeof(Partial));
     w.alpha_cur = (double*)take(K * 8);
     w.g_cur = (double*)take(K * 8);
@@ -271,84 +273,92 @@ __device__ __forceinline__ bool block_any(bool p, BlockShared& sh) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// segment table: column k (k == K is V) gets ceil(len_k / SEG) segments, listed in column order
+// evaluation: one wave per segment
 // ---------------------------------------------------------------------------------------------
-__device__ void build_segments(
-    Ctrl* ctrl, const long long* lenU, const long long* lenV, long long K, long long ldU,
-    long long capV, int* seg_k, int* seg_start, long long* segfirst, long long nseg_max) {
-    __shared__ long long wsum[STEP_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long ncol = K + 1;
-    const long long per = (ncol + STEP_BLOCK - 1) / STEP_BLOCK;
-    const long long k0 = (long long)tid * per, k1 = min(ncol, k0 + per);
-    auto len_of = [&](long long k) {
-        long long L = k < K ? lenU[k] : lenV[0];
-        const long long cap = k < K ? ldU : capV;
-        if (L < 0) L = 0;
-        if (L > cap) L = cap;
-        return L;
-    };
-    long long mine = 0;
-    for (long long k = k0; k < k1; ++k) mine += (len_of(k) + SEG - 1) / SEG;
-    long long sc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        long long up = __shfl_up(sc, d);
-        if (lane >= d) sc += up;
-    }
-    if (lane == 63) wsum[wave] = sc;
-    __syncthreads();
-    long long before = 0, total = 0;
-    for (int w = 0; w < STEP_WAVES; ++w) {
-        if (w < wave) before += wsum[w];
-        total += wsum[w];
-    }
-    long long pos = before + sc - mine;
-    for (long long k = k0; k < k1; ++k) {
-        segfirst[k] = pos;
-        const long long L = len_of(k);
-        for (long long st = 0; st < L; st += SEG) {
-            if (pos < nseg_max) {
-                seg_k[pos] = (int)k;
-                seg_start[pos] = (int)st;
-            }
-            ++pos;
-        }
-    }
-    if (tid == 0) {
-        segfirst[ncol] = total;
-        ctrl->nseg = total < nseg_max ? total : nseg_max;
+struct EvalArgs {  // the statistics as the entry points receive them
+    const double* Uf;
+    long long ldU;
+    const long long* lenU;
+    const double* Vf;
+    long long capV;
+    const long long* lenV;
+};
+
+// What a wave can load for its first segment before the trial point is known (iter_kernel issues
+// these loads at kernel start, beside the loads of the state): the column's length and the wave's
+// four terms per lane.
+struct EvalPrefetch {
+    long long L;
+    double u[SEG / 64];
+};
+
+__device__ __forceinline__ void eval_slot_of(const EvalArgs& e, long long K, long long S, long long s,
+                                             long long& k, long long& st, const double*& u,
+                                             long long& cap) {
+    if (s < K * S) {
+        k = s / S;
+        st = (s - k * S) * SEG;
+        u = e.Uf + k * e.ldU;
+        cap = e.ldU;
+    } else {
+        k = K;
+        st = (s - K * S) * SEG;
+        u = e.Vf;
+        cap = e.capV;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// evaluation: one wave per segment
-// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eval_prefetch(const EvalArgs& e, long long K, long long s,
+                                              long long nslots, EvalPrefetch& pf) {
+    const int lane = threadIdx.x & 63;
+    pf.L = 0;
+#pragma unroll
+    for (int j = 0; j < SEG / 64; ++j) pf.u[j] = 0.0;
+    if (s >= nslots) return;
+    const long long S = slots_per_column(e.ldU);
+    long long k, st, cap;
+    const double* u;
+    eval_slot_of(e, K, S, s, k, st, u, cap);
+    long long L = k < K ? e.lenU[k] : e.lenV[0];
+    pf.L = L > cap ? cap : L;
+#pragma unroll
+    for (int j = 0; j < SEG / 64; ++j) {
+        const long long n = st + lane + 64 * j;
+        if (n < cap) pf.u[j] = u[n];  // within the row's allocation whatever its length
+    }
+}
+
 // Segments s = wave0, wave0 + nwaves, ... of the trial point: the three partial sums of each.
-__device__ __forceinline__ void eval_segments(
-    const Ctrl* ctrl, const int* seg_k, const int* seg_start, const double* Uf, long long ldU,
-    const long long* lenU, const double* Vf, long long capV, const long long* lenV, long long K,
-    const double* alpha, Partial* part, long long wave0, long long nwaves) {
+// pf (or NULL): the prefetched length and terms of segment wave0.
+__device__ __forceinline__ void eval_segments(const Ctrl* ctrl, const EvalArgs& e, long long K,
+                                              const double* alpha, Partial* part, long long wave0,
+                                              long long nwaves, const EvalPrefetch* pf = nullptr) {
     if (ctrl->done || !ctrl->trial_valid) return;
     const int lane = threadIdx.x & 63;
-    const long long nseg = ctrl->nseg;
-    for (long long s = wave0; s < nseg; s += nwaves) {
-        const long long k = seg_k[s];
-        const long long st = seg_start[s];
-        long long L = k < K ? lenU[k] : lenV[0];
-        const long long cap = k < K ? ldU : capV;
+    const long long S = slots_per_column(e.ldU);
+    const long long nslots = K * S + slots_per_column(e.capV);
+    for (long long s = wave0; s < nslots; s += nwaves) {
+        long long k, st, cap;
+        const double* u;
+        eval_slot_of(e, K, S, s, k, st, u, cap);
+        const bool pre = pf != nullptr && s == wave0;
+        long long L = pre ? pf->L : (k < K ? e.lenU[k] : e.lenV[0]);
         if (L > cap) L = cap;
-        const double* u = k < K ? Uf + k * ldU : Vf;
+        if (st >= L) continue;  // wave-uniform: the column ends before this slot
         const double a = k < K ? alpha[k] : ctrl->A_trial;
-        long long end = st + SEG < L ? st + SEG : L;
+        const long long end = st + SEG < L ? st + SEG : L;
         DmeAcc s0{0.0, 0.0}, s1{0.0, 0.0};
         double s2 = 0.0;
-        for (long long n = st + lane; n < end; n += 64) {
-            const double un = u[n];
-            const double x = __dadd_rn(a, (double)n);
-            s0.add(__dmul_rn(un, log(x)));                 // U[k][n] * log(alpha_k + n)   :21 / :25
-            s1.add(__ddiv_rn(un, x));                      // U[k][n] / (alpha_k + n)      :42 / :37
-            s2 = __dadd_rn(s2, __ddiv_rn(un, __dmul_rn(x, x)));  // U/(alpha_k+n)^2       :60 / :53
+#pragma unroll
+        for (int j = 0; j < SEG / 64; ++j) {
+            const long long n = st + lane + 64 * j;
+            if (n < end) {
+                const double un = pre ? pf->u[j] : u[n];
+                const double x = __dadd_rn(a, (double)n);
+                s0.add(__dmul_rn(un, log(x)));                 // U[k][n] * log(alpha_k + n)   :21 / :25
+                s1.add(__ddiv_rn(un, x));                      // U[k][n] / (alpha_k + n)      :42 / :37
+                s2 = __dadd_rn(s2, __ddiv_rn(un, __dmul_rn(x, x)));  // U/(alpha_k+n)^2       :60 / :53
+            }
         }
         s0 = dme_wave_sum_acc(s0);
         s1 = dme_wave_sum_acc(s1);
@@ -360,12 +370,9 @@ __device__ __forceinline__ void eval_segments(
     }
 }
 
-__global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(
-    const Ctrl* ctrl, const int* seg_k, const int* seg_start, const double* Uf, long long ldU,
-    const long long* lenU, const double* Vf, long long capV, const long long* lenV, long long K,
-    const double* alpha, Partial* part) {
-    eval_segments(ctrl, seg_k, seg_start, Uf, ldU, lenU, Vf, capV, lenV, K, alpha, part,
-                  ((long long)blockIdx.x * EVAL_BLOCK + threadIdx.x) >> 6,
+__global__ __launch_bounds__(EVAL_BLOCK) void eval_kernel(const Ctrl* ctrl, EvalArgs e, long long K,
+                                                          const double* alpha, Partial* part) {
+    eval_segments(ctrl, e, K, alpha, part, ((long long)blockIdx.x * EVAL_BLOCK + threadIdx.x) >> 6,
                   ((long long)gridDim.x * EVAL_BLOCK) >> 6);
 }
 
@@ -384,26 +391,79 @@ struct Gathered {
     double sumLgamma;       // sum lgamma(alpha_k)      (CPT/dme.py:38),    0 without W
 };
 
+// The partial sums one thread gathers, loaded before they are needed (iter_kernel: at kernel start,
+// beside the state): the slots of its NCOL columns k = tid, tid + STEP_BLOCK, ... (at most PF_SMAX
+// each) and, for thread t < SV, slot t of V.  Loaded whatever the columns' lengths turn out to be -
+// the table holds every slot - and masked by the lengths afterwards.
+constexpr int PF_SMAX = 2;  // prefetch covers ldU <= 2 * SEG = 512 count bins
+struct PartV {
+    double v[5];  // s0hi, s0lo, s1hi, s1lo, s2
+};
+__device__ __forceinline__ PartV ld_part(const Partial* p) {
+    return PartV{{p->s0hi, p->s0lo, p->s1hi, p->s1lo, p->s2}};
+}
+template <int NCOL>
+struct GatherPrefetch {
+    long long L[NCOL > 0 ? NCOL : 1];
+    PartV p[NCOL > 0 ? NCOL : 1];  // slot 0 of each column (most columns end there); others on demand
+    long long LV;
+    PartV pv;
+};
+
+template <int NCOL>
+__device__ __forceinline__ void gather_prefetch(const EvalArgs& e, const Partial* part, long long K,
+                                                GatherPrefetch<NCOL>& pf) {
+    const int tid = threadIdx.x;
+    const long long S = slots_per_column(e.ldU), SV = slots_per_column(e.capV);
+    long long lv = e.lenV[0];
+    pf.LV = lv > e.capV ? e.capV : lv;
+    pf.pv = PartV{{0, 0, 0, 0, 0}};
+    if (tid < SV) pf.pv = ld_part(part + K * S + tid);
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const long long k = tid + (long long)c * STEP_BLOCK;
+        pf.L[c] = 0;
+        pf.p[c] = PartV{{0, 0, 0, 0, 0}};
+        if (k < K) {
+            long long L = e.lenU[k];
+            pf.L[c] = L > e.ldU ? e.ldU : L;
+            pf.p[c] = ld_part(part + k * S);
+        }
+    }
+}
+
 // Per-column sums at the evaluated point -> g_out[k], d_out[k]; returns the block totals.
 // Two fused block reductions: the V sums first (the gradient needs them), then everything per k.
 // CPT = false compiles the (Beta, W) terms out, so the scalar-hyperprior kernels keep their
 // register budget (116 VGPRs against 256 + spills with digamma / trigamma / lgamma inlined).
-template <bool CPT>
-__device__ Gathered gather_eval(const Ws& w, long long K, double A, const Prior& pr,
-                                const double* alpha, double* g_out, double* d_out,
-                                BlockShared& sh) {
+// NCOL > 0: the partial sums come from `pf` (gather_prefetch; needs K <= NCOL * STEP_BLOCK,
+// S <= PF_SMAX, SV <= STEP_BLOCK); NCOL == 0: from the table.  Same values, same order.
+template <bool CPT, int NCOL>
+__device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, double A,
+                                const Prior& pr, const double* alpha, double* g_out, double* d_out,
+                                BlockShared& sh, const GatherPrefetch<NCOL>* pf) {
     Gathered G;
     const int tid = threadIdx.x;
+    const long long S = slots_per_column(e.ldU);
     // V = column K
     {
-        const long long f = w.segfirst[K], l = w.segfirst[K + 1];
+        long long LV;
+        if constexpr (NCOL > 0) {
+            LV = pf->LV;
+        } else {
+            LV = e.lenV[0];
+            if (LV > e.capV) LV = e.capV;
+        }
+        const long long nv = LV > 0 ? (LV + SEG - 1) / SEG : 0;
         DmeAcc a[2] = {{0, 0}, {0, 0}};
         double d[1] = {0.0};
-        for (long long s = f + tid; s < l; s += STEP_BLOCK) {
-            const Partial p = w.part[s];
-            a[0].add(DmeAcc{p.s0hi, p.s0lo});
-            a[1].add(DmeAcc{p.s1hi, p.s1lo});
-            d[0] = __dadd_rn(d[0], p.s2);
+        for (long long i = tid; i < nv; i += STEP_BLOCK) {
+            PartV p;
+            if constexpr (NCOL > 0) p = pf->pv;  // SV <= STEP_BLOCK: i == tid
+            else p = ld_part(w.part + K * S + i);
+            a[0].add(DmeAcc{p.v[0], p.v[1]});
+            a[1].add(DmeAcc{p.v[2], p.v[3]});
+            d[0] = __dadd_rn(d[0], p.v[4]);
         }
         bool none = false;
         block_reduce_fused<2, 1>(a, d, none, sh);
@@ -422,16 +482,7 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, const Prior&
     constexpr int NR = CPT ? 5 : 3;
     double r[NR] = {};  // gradSq, numSum, denSum, sum a*Beta, sum lgamma(a)
     bool zero = false;
-    for (long long k = tid; k < K; k += STEP_BLOCK) {
-        const long long f = w.segfirst[k], l = w.segfirst[k + 1];
-        DmeAcc a0{0, 0}, a1{0, 0};
-        double a2 = 0.0;
-        for (long long s = f; s < l; ++s) {
-            const Partial p = w.part[s];
-            a0.add(DmeAcc{p.s0hi, p.s0lo});
-            a1.add(DmeAcc{p.s1hi, p.s1lo});
-            a2 = __dadd_rn(a2, p.s2);
-        }
+    auto column = [&](long long k, const DmeAcc& a0, const DmeAcc& a1, double a2) {
         ls[0].add(a0);
         double g = __dsub_rn(a1.value(), termToSubtract);  // :45
         g = __dadd_rn(g, hs);                              // :46
@@ -455,6 +506,40 @@ __device__ Gathered gather_eval(const Ws& w, long long K, double A, const Prior&
         } else {
             r[1] = __dadd_rn(r[1], __ddiv_rn(g, dk));
             r[2] = __dadd_rn(r[2], __ddiv_rn(1.0, dk));
+        }
+    };
+    if constexpr (NCOL > 0) {
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) {
+            const long long k = tid + (long long)c * STEP_BLOCK;
+            if (k < K) {
+                const long long L = pf->L[c];
+                const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
+                DmeAcc a0{0, 0}, a1{0, 0};
+                double a2 = 0.0;
+                for (long long i = 0; i < cnt; ++i) {
+                    const PartV p = i == 0 ? pf->p[c] : ld_part(w.part + k * S + i);
+                    a0.add(DmeAcc{p.v[0], p.v[1]});
+                    a1.add(DmeAcc{p.v[2], p.v[3]});
+                    a2 = __dadd_rn(a2, p.v[4]);
+                }
+                column(k, a0, a1, a2);
+            }
+        }
+    } else {
+        for (long long k = tid; k < K; k += STEP_BLOCK) {
+            long long L = e.lenU[k];
+            if (L > e.ldU) L = e.ldU;
+            const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
+            DmeAcc a0{0, 0}, a1{0, 0};
+            double a2 = 0.0;
+            for (long long i = 0; i < cnt; ++i) {
+                const PartV p = ld_part(w.part + k * S + i);
+                a0.add(DmeAcc{p.v[0], p.v[1]});
+                a1.add(DmeAcc{p.v[2], p.v[3]});
+                a2 = __dadd_rn(a2, p.v[4]);
+            }
+            column(k, a0, a1, a2);
         }
     }
     block_reduce_fused<1, NR>(ls, r, zero, sh);
@@ -558,7 +643,7 @@ __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
     return !bad;
 }
 
-// Segment table of the statistics (build_segments) and the start state of the loop, one launch.
+// The start state of the loop, one launch.
 // init_acc != NULL: the start point is the CLI's (DE/fdp.py:104-108) computed here from the mean
 // accumulators, with dme_cli_init_alphas' own arithmetic (same bits), instead of being read from
 // `alpha`.  status != NULL: the statistics pass's status words ride along in result[8..16), so one
@@ -573,9 +658,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
     const int tid = threadIdx.x;
     if (result && tid < 8) result[tid] = 0;  // [6] is the done word the host polls
     if (result && status && tid < 8) result[8 + tid] = (long long)status[tid];
-    build_segments(w.ctrl, lenU, lenV, K, ldU, capV, w.seg_k, w.seg_start, w.segfirst, w.nseg_max);
     if (tid == 0) {
         Ctrl* c = w.ctrl;
+        c->nseg = w.nseg_max;
         c->done = 0; c->phase = phase; c->count = 0; c->n_evals = 0; c->exit_reason = 0;
         c->error = 0; c->launches = 0; c->branch = 0; c->currentLoss = 0.0; c->learnRate = 1.0;
         c->hconst_cur = 0.0; c->fragile = 0;
@@ -594,11 +679,20 @@ __global__ __launch_bounds__(STEP_BLOCK) void setup_kernel(Ws w, const double* a
 // One round of the state machine of findDirichletPriors: consumes the evaluation of the trial
 // point, decides, and leaves the next trial point (or the result).  Called by every thread of a
 // STEP_BLOCK workgroup.
-template <bool CPT>
-__device__ void step_body(const Ws& w, long long K, long long iterations, const Prior& pr,
-                          double* trace, double* trace_alpha, long long trace_cap,
+// iter_kernel keeps the state in LDS and loads the CURRENT point's vectors only when a launch needs
+// them: an accepted trial overwrites them, so the common launch (Newton step accepted) never does.
+struct LazyCur {
+    const double* alpha_cur;
+    const double* g_cur;
+    const double* d_cur;
+};
+
+template <bool CPT, int NCOL = 0>
+__device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long iterations,
+                          const Prior& pr, double* trace, double* trace_alpha, long long trace_cap,
                           double* alpha_out, long long* result, double* final_loss,
-                          BlockShared& sh, const bool writer = true) {
+                          BlockShared& sh, const bool writer = true,
+                          const GatherPrefetch<NCOL>* pf = nullptr, const LazyCur* lz = nullptr) {
     // `writer`: this workgroup publishes the outputs (alpha_out, result, final_loss, the trace).  In
     // iter_kernel every workgroup runs this function redundantly on its own LDS copy of the state and
     // only workgroup 0 writes.
@@ -619,7 +713,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
     double hconstT = 0.0;
     Gathered G{};
     if (valid) {
-        G = gather_eval<CPT>(w, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh);
+        G = gather_eval<CPT, NCOL>(w, e, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh, pf);
         lossT = loss_from<CPT>(G, A, pr);
         hconstT = G.t2;
         n_evals += 1;
@@ -657,6 +751,15 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
         }
     };
 
+    // (a thread only ever touches its own columns k = tid, tid + STEP_BLOCK, ... of these vectors)
+    auto need_cur = [&]() {
+        if (lz)
+            for (long long k = tid; k < K; k += STEP_BLOCK) {
+                w.alpha_cur[k] = lz->alpha_cur[k];
+                w.g_cur[k] = lz->g_cur[k];
+                w.d_cur[k] = lz->d_cur[k];
+            }
+    };
     bool accept = false;
     if (phase == PH_INIT) {
         if (!valid) {  // math.log(x <= 0) -> ValueError at DE/dme.py:131
@@ -674,6 +777,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
             branch = 1;
         } else {
             // :165-172 log-space trial from the CURRENT point's gradient / Hessian
+            need_cur();
             const bool ok = logspace_trial(w.alpha_cur, w.g_cur, w.d_cur, c->hconst_cur, K,
                                            w.alpha_trial, nullptr, sh);
             if (!ok) { finish(0, DME_ERR_ZERO_DIVISION); return; }
@@ -684,6 +788,7 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
             return;
         }
     } else {  // PH_LOGSPACE / PH_HALVING: the while loop of :176-180
+        need_cur();
         if (lossT > currentLoss) {
             // A trial with an alpha <= 0 scores inf without an evaluation (:98-100) and the loop
             // goes on: those rounds are walked here instead of costing a launch pair each (a bad
@@ -772,13 +877,13 @@ __device__ void step_body(const Ws& w, long long K, long long iterations, const 
 }
 
 template <bool CPT>
-__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, long long iterations,
-                                                          Prior pr, double* trace,
-                                                          double* trace_alpha, long long trace_cap,
-                                                          double* alpha_out, long long* result,
-                                                          double* final_loss) {
+__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, EvalArgs e, long long K,
+                                                          long long iterations, Prior pr,
+                                                          double* trace, double* trace_alpha,
+                                                          long long trace_cap, double* alpha_out,
+                                                          long long* result, double* final_loss) {
     __shared__ BlockShared sh;
-    step_body<CPT>(w, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
+    step_body<CPT>(w, e, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
                    final_loss, sh);
 }
 
@@ -786,15 +891,6 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(Ws w, long long K, lon
 // the whole loop in ONE launch.  The workgroup's eight waves evaluate the segments, a barrier,
 // the same step_body, a barrier, and again - the arithmetic and its order are those of the
 // eval_kernel / step_kernel chain, whose ~10 us per round was launch overhead on such inputs.
-struct EvalArgs {
-    const double* Uf;
-    long long ldU;
-    const long long* lenU;
-    const double* Vf;
-    long long capV;
-    const long long* lenV;
-};
-
 template <bool CPT>
 __global__ __launch_bounds__(STEP_BLOCK) void small_solve_kernel(Ws w, EvalArgs e, long long K,
                                                                  long long iterations, Prior pr,
@@ -806,10 +902,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void small_solve_kernel(Ws w, EvalArgs 
     __shared__ BlockShared sh;
     const long long wave = threadIdx.x >> 6;
     for (long long round = 0;; ++round) {
-        eval_segments(w.ctrl, w.seg_k, w.seg_start, e.Uf, e.ldU, e.lenU, e.Vf, e.capV, e.lenV, K,
-                      w.alpha_trial, w.part, wave, STEP_WAVES);
+        eval_segments(w.ctrl, e, K, w.alpha_trial, w.part, wave, STEP_WAVES);
         __syncthreads();
-        step_body<CPT>(w, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
+        step_body<CPT>(w, e, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
                        final_loss, sh);
         __syncthreads();
         if (((volatile Ctrl*)w.ctrl)->done) break;
@@ -825,65 +920,108 @@ __global__ __launch_bounds__(STEP_BLOCK) void small_solve_kernel(Ws w, EvalArgs 
 }
 
 // Mid-size problems (K up to FUSED_KMAX columns, more segments than one workgroup evaluates well):
-// ONE launch per evaluation instead of an (eval, step) pair.  Launch j first consumes the partial
-// sums of evaluation j - 1: EVERY workgroup runs the same step_body redundantly on its own LDS copy
-// of the state (control block + the six K-vectors), so every workgroup knows the next trial point
-// without any hand-off inside the launch; then the workgroups share out the segments of that
-// point's evaluation.  Only workgroup 0 writes the state and the outputs, into the copy the next
-// launch reads (two copies, alternating: no workgroup reads what another one writes in the same
-// launch).  Same device functions, same order of operations as the pair chain: the same bits
-// (test_single_launch_and_chained_solvers_agree_bit_for_bit).  Each launch saved is ~4.5 us of the
-// solver's critical path (profiles/r2_notes.md).
+// ONE launch per evaluation instead of an (eval, step) pair, and no set-up launch.  Launch j first
+// consumes the partial sums of evaluation j - 1: EVERY workgroup runs the same step_body redundantly
+// on its own LDS copy of the state (control block + the six K-vectors), so every workgroup knows the
+// next trial point without any hand-off inside the launch; then the workgroups share out the
+// segments of that point's evaluation.  Only workgroup 0 writes the state and the outputs, into the
+// copy the next launch reads (two copies, alternating: no workgroup reads what another one writes
+// in the same launch).  Launch 0 builds the start state instead of a step (from `alpha`, or from
+// the CLI's mean accumulators).  Everything a launch needs from memory that does not depend on its
+// own arithmetic - the state, the partial sums its threads gather (NCOL > 0), the terms of each
+// wave's first segment - is loaded in ONE round at kernel start: a launch's critical path is one
+// memory round trip, the step's block reductions and one segment's arithmetic.  Same device
+// functions, same order of operations as the pair chain: the same bits
+// (test_single_launch_and_chained_solvers_agree_bit_for_bit).  profiles/r2_notes.md has the times.
 constexpr long long FUSED_KMAX = 2048;  // 6 K-vectors in LDS: 96 KiB
 
-template <bool CPT>
-__global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, long long K,
-                                                          long long iterations, Prior pr,
-                                                          double* trace, double* trace_alpha,
-                                                          long long trace_cap, double* alpha_out,
-                                                          long long* result, double* final_loss,
-                                                          int parity, int first) {
+struct IterArgs {
+    long long K, iterations;
+    double* trace;
+    double* trace_alpha;
+    long long trace_cap;
+    double* alpha;             // in (launch 0, when init_acc is NULL) / out
+    long long* result;
+    double* final_loss;
+    const double* init_acc;    // launch 0: CLI start point from the mean accumulators, or NULL
+    const u64* status;         // launch 0: copied to result[8..16), or NULL
+    int parity, first;
+};
+
+template <bool CPT, int NCOL>
+__global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prior pr, IterArgs a) {
     extern __shared__ __attribute__((aligned(16))) double kvec[];  // [6][K]
     __shared__ BlockShared sh;
     __shared__ Ctrl lc;
     const int tid = threadIdx.x;
+    const long long K = a.K;
+    const int parity = a.parity;
+    const bool first = a.first != 0;
+    const bool writer = blockIdx.x == 0;
     const Ctrl* cin = parity ? w.ctrl2 : w.ctrl;
     Ctrl* cout = parity ? w.ctrl : w.ctrl2;
-    if (cin->done) {  // uniform over the grid: the solve ended in an earlier launch
-        if (blockIdx.x == 0 && tid == 0) cout->done = 1;  // the launch after this one reads `cout`
-        return;
-    }
-    const double* in_acur = parity ? w.alpha_cur2 : w.alpha_cur;
-    const double* in_gcur = parity ? w.g_cur2 : w.g_cur;
-    const double* in_dcur = parity ? w.d_cur2 : w.d_cur;
-    const double* in_atr = parity ? w.alpha_trial2 : w.alpha_trial;
+    const Partial* part_in = parity ? w.part2 : w.part;
+    Partial* part_out = parity ? w.part : w.part2;
     double* l_acur = kvec;
     double* l_gcur = kvec + K;
     double* l_dcur = kvec + 2 * K;
     double* l_atr = kvec + 3 * K;
-    if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)&lc)[tid] = ((const long long*)cin)[tid];
-    for (long long k = tid; k < K; k += STEP_BLOCK) {
-        l_atr[k] = in_atr[k];
-        if (!first) {  // the first launch only evaluates the start point
-            l_acur[k] = in_acur[k];
-            l_gcur[k] = in_gcur[k];
-            l_dcur[k] = in_dcur[k];
+    const long long wave0 = (long long)blockIdx.x * STEP_WAVES + (tid >> 6);
+    const long long nslots = K * slots_per_column(e.ldU) + slots_per_column(e.capV);
+
+    // ---- one round of loads: this wave's first segment, this thread's partial sums, the state -----
+    EvalPrefetch epf;
+    eval_prefetch(e, K, wave0, nslots, epf);
+    GatherPrefetch<NCOL> gpf;
+    if constexpr (NCOL > 0)
+        if (!first) gather_prefetch<NCOL>(e, part_in, K, gpf);
+    if (first) {
+        // the start state (what setup_kernel builds for the other launch structures)
+        if (tid == 0) {
+            Ctrl z{};
+            z.phase = PH_INIT;
+            z.learnRate = 1.0;
+            z.nseg = nslots;
+            lc = z;
         }
+        if (a.init_acc) {
+            const double priorSum = dme_cli_prior_sum<STEP_BLOCK>(a.init_acc, K, sh.dbl);
+            for (long long k = tid; k < K; k += STEP_BLOCK)
+                l_atr[k] = __dadd_rn(__ddiv_rn(a.init_acc[k], priorSum), 0.01);
+        } else {
+            for (long long k = tid; k < K; k += STEP_BLOCK) l_atr[k] = a.alpha[k];
+        }
+        __syncthreads();
+        finish_trial(&lc, l_atr, K, sh);
+        if (writer && tid < 8) {
+            a.result[tid] = 0;  // [6] is the done word the host polls
+            if (a.status) a.result[8 + tid] = (long long)a.status[tid];
+        }
+    } else {
+        const double* in_acur = parity ? w.alpha_cur2 : w.alpha_cur;
+        const double* in_gcur = parity ? w.g_cur2 : w.g_cur;
+        const double* in_dcur = parity ? w.d_cur2 : w.d_cur;
+        const double* in_atr = parity ? w.alpha_trial2 : w.alpha_trial;
+        if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)&lc)[tid] = ((const long long*)cin)[tid];
+        for (long long k = tid; k < K; k += STEP_BLOCK) l_atr[k] = in_atr[k];
+        const LazyCur lz{in_acur, in_gcur, in_dcur};
+        __syncthreads();
+        if (lc.done) {  // uniform over the grid: the solve ended in an earlier launch
+            if (writer && tid == 0) cout->done = 1;  // the launch after this one reads `cout`
+            return;
+        }
+        Ws lw = w;
+        lw.ctrl = &lc;
+        lw.alpha_cur = l_acur;
+        lw.g_cur = l_gcur;
+        lw.d_cur = l_dcur;
+        lw.alpha_trial = l_atr;
+        lw.g_trial = kvec + 4 * K;
+        lw.d_trial = kvec + 5 * K;
+        lw.part = const_cast<Partial*>(part_in);
+        step_body<CPT, NCOL>(lw, e, K, a.iterations, pr, a.trace, a.trace_alpha, a.trace_cap, a.alpha,
+                             a.result, a.final_loss, sh, writer, NCOL > 0 ? &gpf : nullptr, &lz);
     }
-    __syncthreads();
-    Ws lw = w;
-    lw.ctrl = &lc;
-    lw.alpha_cur = l_acur;
-    lw.g_cur = l_gcur;
-    lw.d_cur = l_dcur;
-    lw.alpha_trial = l_atr;
-    lw.g_trial = kvec + 4 * K;
-    lw.d_trial = kvec + 5 * K;
-    lw.part = parity ? w.part2 : w.part;
-    const bool writer = blockIdx.x == 0;
-    if (!first)
-        step_body<CPT>(lw, K, iterations, pr, trace, trace_alpha, trace_cap, alpha_out, result,
-                       final_loss, sh, writer);
     __syncthreads();
     if (writer) {
         if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)cout)[tid] = ((const long long*)&lc)[tid];
@@ -902,16 +1040,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, long
     }
     // the evaluation of the new trial point (nothing to do once done, or for a trial with an
     // alpha <= 0, which scores inf without an evaluation: eval_segments checks both)
-    eval_segments(&lc, w.seg_k, w.seg_start, e.Uf, e.ldU, e.lenU, e.Vf, e.capV, e.lenV, K, l_atr,
-                  parity ? w.part : w.part2,
-                  (long long)blockIdx.x * STEP_WAVES + (threadIdx.x >> 6),
-                  (long long)gridDim.x * STEP_WAVES);
+    eval_segments(&lc, e, K, l_atr, part_out, wave0, (long long)gridDim.x * STEP_WAVES, &epf);
 }
 
 // dme_eval epilogue: publish the evaluated quantities
 template <bool CPT>
-__global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long long K, Prior pr,
-                                                                  double* out_scalars,
+__global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, EvalArgs e, long long K,
+                                                                  Prior pr, double* out_scalars,
                                                                   double* out_grad,
                                                                   double* out_hdiag) {
     __shared__ BlockShared sh;
@@ -926,7 +1061,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void publish_eval_kernel(Ws w, long lon
         if (tid == 0) { out_scalars[0] = NAN; out_scalars[1] = NAN; out_scalars[2] = A; out_scalars[3] = NAN; }
         return;
     }
-    const Gathered G = gather_eval<CPT>(w, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh);
+    const Gathered G = gather_eval<CPT, 0>(w, e, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh,
+                                           (const GatherPrefetch<0>*)nullptr);
     const double loss = loss_from<CPT>(G, A, pr);
     for (long long k = tid; k < K; k += STEP_BLOCK) {
         if (out_grad) out_grad[k] = w.g_trial[k];
@@ -1014,15 +1150,16 @@ int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
                        (long long)ldU, (long long)capV, (long long*)nullptr, (const double*)nullptr,
                        (const u64*)nullptr);
     // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
-    hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s, w.ctrl,
-                       w.seg_k, w.seg_start, Uf, (long long)ldU, (const long long*)lenU, Vf,
-                       (long long)capV, (const long long*)lenV, (long long)K, w.alpha_trial, w.part);
+    const EvalArgs ea{Uf, (long long)ldU, (const long long*)lenU, Vf, (long long)capV,
+                      (const long long*)lenV};
+    hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s,
+                       (const Ctrl*)w.ctrl, ea, (long long)K, (const double*)w.alpha_trial, w.part);
     const bool cpt = pr.beta != nullptr || pr.has_W;
     if (cpt)
-        hipLaunchKernelGGL(publish_eval_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+        hipLaunchKernelGGL(publish_eval_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
                            (long long)K, pr, out_scalars, out_grad, out_hdiag);
     else
-        hipLaunchKernelGGL(publish_eval_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w,
+        hipLaunchKernelGGL(publish_eval_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea,
                            (long long)K, pr, out_scalars, out_grad, out_hdiag);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
@@ -1056,8 +1193,8 @@ extern "C" int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, 
 // device array instead.  Every GPU holds its own copy of the array at its own address, so the
 // address is looked up once per device with hipGetSymbolAddress (with that device current) and only
 // that pointer - never the array's name, which is a host-side stand-in - is handed to kernels.
-// Nothing in it has to start at zero: setup_kernel writes the whole control block and the segment
-// table, eval_kernel writes every partial that the gather later reads.  Calls that overlap on one
+// Nothing in it has to start at zero: setup_kernel writes the whole control block, eval_kernel writes
+// every partial that the gather later reads (slots beyond a column's length are never read).  Calls that overlap on one
 // GPU (two streams, two threads) race on the array.
 // ---------------------------------------------------------------------------------------------
 constexpr long long kNoAllocScratchBytes = DME_NOALLOC_SCRATCH_BYTES;  // 8 MiB per GPU, held until the process ends
@@ -1176,15 +1313,43 @@ int pick_path(long long K, long long nseg_max) {
 // every reference iteration costs at most 2 + ~400 evaluations (0.9^n underflows the step)
 long long max_launches(long long iterations) { return (iterations + 2) * 450 + 16; }
 
-// Enqueues launches [first, first + count) of a solve on `s` (launch 0 is preceded by the set-up
-// kernel).  What one launch is depends on the structure: FUSED - one iter_kernel (the first only
-// evaluates the start point, so n evaluations take n + 1 launches); CHAIN - an (eval, step) pair;
-// SINGLE - the whole loop (first == 0 only; count is ignored).  Nothing is waited for.
+template <bool CPT, int NCOL>
+int launch_iter(const Ws& w, const EvalArgs& ea, const Prior& pr, const IterArgs& a, unsigned grid,
+                size_t lds, hipStream_t s) {
+    auto kern = iter_kernel<CPT, NCOL>;
+    static bool attr_set[64] = {};  // per instantiation and device
+    int dev = 0;
+    DME_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(6 * FUSED_KMAX * 8)));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_BLOCK), lds, s, w, ea, pr, a);
+    return DME_OK;
+}
+
+template <bool CPT>
+int launch_iter_ncol(int ncol, const Ws& w, const EvalArgs& ea, const Prior& pr, const IterArgs& a,
+                     unsigned grid, size_t lds, hipStream_t s) {
+    switch (ncol) {
+        case 1: return launch_iter<CPT, 1>(w, ea, pr, a, grid, lds, s);
+        case 2: return launch_iter<CPT, 2>(w, ea, pr, a, grid, lds, s);
+        case 4: return launch_iter<CPT, 4>(w, ea, pr, a, grid, lds, s);
+        default: return launch_iter<CPT, 0>(w, ea, pr, a, grid, lds, s);
+    }
+}
+
+// Enqueues launches [first, first + count) of a solve on `s`.  What one launch is depends on the
+// structure: FUSED - one iter_kernel (launch 0 builds the start state and evaluates it, so n
+// evaluations take n + 1 launches); CHAIN - an (eval, step) pair, launch 0 preceded by the set-up
+// kernel; SINGLE - set-up and the whole loop (first == 0 only; count is ignored).  Nothing is
+// waited for.
 int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first, long long count,
                      hipStream_t s) {
     const bool cpt = c.pr.beta != nullptr || c.pr.has_W;
     const EvalArgs ea{c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV};
-    if (first == 0) {
+    if (first == 0 && path != DME_SOLVE_PATH_FUSED) {
         hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)c.alpha,
                            c.K, (long long)PH_INIT, c.lenU, c.lenV, c.ldU, c.capV, c.result,
                            c.init_acc, c.status);
@@ -1203,15 +1368,6 @@ int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first,
                                c.result, c.final_loss, rounds);
     } else if (path == DME_SOLVE_PATH_FUSED) {
         const size_t lds = (size_t)(6 * c.K * 8);
-        int dev = 0;
-        DME_HIP_CHECK(hipGetDevice(&dev));
-        static bool attr_set[2][64] = {};
-        if (dev < 0 || dev >= 64 || !attr_set[cpt ? 1 : 0][dev]) {
-            const void* fn = cpt ? (const void*)iter_kernel<true> : (const void*)iter_kernel<false>;
-            DME_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(6 * FUSED_KMAX * 8)));
-            if (dev >= 0 && dev < 64) attr_set[cpt ? 1 : 0][dev] = true;
-        }
         // one wave per segment and round; every workgroup repeats the step, so no more of them than
         // the evaluation can use
         int cus = dme_device_cus();
@@ -1219,29 +1375,28 @@ int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first,
         long long fg = (w.nseg_max + STEP_WAVES - 1) / STEP_WAVES;
         if (fg > cus) fg = cus;
         if (fg < 1) fg = 1;
+        // the gathered partial sums are prefetched when a thread's share is small and fixed
+        int ncol = 0;
+        if (slots_per_column(c.ldU) <= PF_SMAX && slots_per_column(c.capV) <= STEP_BLOCK)
+            ncol = c.K <= STEP_BLOCK ? 1 : (c.K <= 2 * STEP_BLOCK ? 2 : 4);
         for (long long j = first; j < first + count; ++j) {
-            const int parity = (int)(j & 1), is_first = j == 0 ? 1 : 0;
-            if (cpt)
-                hipLaunchKernelGGL(iter_kernel<true>, dim3((unsigned)fg), dim3(STEP_BLOCK), lds, s, w,
-                                   ea, c.K, c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap,
-                                   c.alpha, c.result, c.final_loss, parity, is_first);
-            else
-                hipLaunchKernelGGL(iter_kernel<false>, dim3((unsigned)fg), dim3(STEP_BLOCK), lds, s, w,
-                                   ea, c.K, c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap,
-                                   c.alpha, c.result, c.final_loss, parity, is_first);
+            const IterArgs a{c.K, c.iterations, c.trace, c.trace_alpha, c.trace_cap, c.alpha, c.result,
+                             c.final_loss, c.init_acc, c.status, (int)(j & 1), j == 0 ? 1 : 0};
+            const int rc = cpt ? launch_iter_ncol<true>(ncol, w, ea, c.pr, a, (unsigned)fg, lds, s)
+                               : launch_iter_ncol<false>(ncol, w, ea, c.pr, a, (unsigned)fg, lds, s);
+            if (rc) return rc;
         }
     } else {
         const unsigned grid = eval_grid(w.nseg_max);
         for (long long j = first; j < first + count; ++j) {
-            hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, w.ctrl, w.seg_k,
-                               w.seg_start, c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K,
-                               w.alpha_trial, w.part);
+            hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVAL_BLOCK), 0, s, (const Ctrl*)w.ctrl, ea,
+                               c.K, (const double*)w.alpha_trial, w.part);
             if (cpt)
-                hipLaunchKernelGGL(step_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, c.K,
+                hipLaunchKernelGGL(step_kernel<true>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea, c.K,
                                    c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
                                    c.result, c.final_loss);
             else
-                hipLaunchKernelGGL(step_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, c.K,
+                hipLaunchKernelGGL(step_kernel<false>, dim3(1), dim3(STEP_BLOCK), 0, s, w, ea, c.K,
                                    c.iterations, c.pr, c.trace, c.trace_alpha, c.trace_cap, c.alpha,
                                    c.result, c.final_loss);
         }
