@@ -29,6 +29,12 @@
 // too small to repay six launches, the atomics kernel runs.
 #include "dme_common.h"
 
+// dme_csr2.hip: the second design, for K <= 65 536 columns
+long long dme_csr2_workspace_bytes(long long N, long long nnz, long long K);
+int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, long long N, long long nnz,
+                 long long K, u64* hist, long long nbins, u64* histV, long long tbins, double* init_acc,
+                 u64* status, void* workspace, long long workspace_bytes, hipStream_t s);
+
 namespace {
 
 constexpr int CSR_BLOCK = 1024;
@@ -839,6 +845,8 @@ __global__ __launch_bounds__(CSR_BLOCK) void csr_reduce_kernel(BucketArgs a) {
 
 extern "C" int64_t dme_stats_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t K) {
     if (N <= 0 || K <= 0 || nnz < CSR_SMALL_NNZ || nnz >= (1LL << 32)) return 0;
+    const long long b2 = dme_csr2_workspace_bytes(N, nnz, K);
+    if (b2 > 0) return b2;  // K <= 65 536: the second design (dme_csr2.hip)
     CsrPlan p;
     if (plan_csr(N, nnz, K, 2, &p) != DME_OK) return 0;
     return p.bytes;
@@ -859,6 +867,12 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     CsrPlan p;
     // the scatter kernel addresses a slab's entries with 32-bit offsets
     bool partitioned = workspace != nullptr && nnz >= CSR_SMALL_NNZ && nnz < (1LL << 32);
+    if (partitioned) {
+        const int rc2 = dme_csr2_run((const long long*)rowptr, colidx, vals, N, nnz, K, (u64*)hist, nbins,
+                                     (u64*)histV, tbins, init_acc, (u64*)status, workspace,
+                                     workspace_bytes, s);
+        if (rc2 >= 0) return rc2;  // -1: more than 65 536 columns, the first design below
+    }
     if (partitioned) {
         if (plan_csr(N, nnz, K, nbins, &p) != DME_OK) partitioned = false;  // K beyond the buckets
         else

@@ -1,0 +1,751 @@
+// dme_csr2.hip — statistics pass over CSR rows for vocabularies of up to 65 536 columns (the
+// bag-of-words shape of BASELINE configs[3]: K = 50 000), second design.
+//
+// Reference semantics as in dme_csr.hip: CompressedRowData.appendRow over every row
+// (DE/dme.py:113-123) and the CLI's mean accumulator (DE/fdp.py:87-89):
+//   hist[k][v] += 1 per stored entry (k, v > 0),  histV[n_i] += 1,  init_acc[k] += v / (1 + n_i).
+//
+// The first design (dme_csr.hip: count pass, offsets, workgroup-wide radix batches behind six
+// barriers each, 8-byte records) moved 4.5x the algorithmic bytes and ran at 8 % of the HBM peak.
+// Here the entries cross memory twice, as 4-byte records, and no workgroup barrier sits on the path:
+//
+//   csr2_part_kernel    ONE WAVE OWNS A ROW: its lanes load the row's entries, the row total is a DPP
+//                       wave reduction, and every entry becomes a 32-bit record
+//                       {column-in-bucket : 10 | count : 8 | row total : 14} of its column bucket
+//                       (1024 consecutive columns or fewer; at most 64 buckets).  Records are staged
+//                       in wave-private LDS rings, one per bucket, and leave in aligned 64-byte units
+//                       (16 records) to the wave's open chunk of that bucket; chunks (4 KiB) come
+//                       from the workgroup's own range of chunk ids (sized from its rows' entries),
+//                       so no counting pass and no global allocation counter are needed.
+//                       Entries a record cannot hold (count >= 256 or row total >= 16384) go to
+//                       global atomics.                                   [reads all, writes 4 B/entry]
+//   csr2_sort_kernel    lists the chunks bucket by bucket (a counting sort of <= a few 1e5 ids)
+//   csr2_bucket_kernel  the bucket-ordered chunk list is cut into equal pieces, one per workgroup; a
+//                       piece counts its records in an LDS image of its bucket (32-bit bins
+//                       1..BL per column, fp64 mean accumulators) and dumps the image of every
+//                       (bucket, piece) run                                         [reads 4 B/entry]
+//   csr2_reduce_kernel  adds the images of each bucket into hist / init_acc
+//
+// Integer results are exact and order-independent; init_acc is summed in arrival order (fp64), so
+// its last bits vary from run to run, as on the other CSR paths.  A malformed rowptr (negative,
+// decreasing, beyond nnz) is flagged in status[6]; such rows are not read, and rows that overlap
+// can never overrun the workspace: the chunk pool refuses allocations beyond its size.
+#include "dme_common.h"
+
+namespace dme_csr2 {
+
+constexpr int PBLOCK = 1024;           // partition kernel: 16 waves, one workgroup per CU
+constexpr int PWAVES = PBLOCK / 64;
+constexpr int MAXB = 64;               // buckets at most (one lane per bucket)
+constexpr int UNIT = 16;               // records per flush unit (64 bytes)
+constexpr int RING = 32;               // records a (wave, bucket) ring holds
+constexpr int CHUNK = 1024;            // records per chunk (4 KiB)
+constexpr int TBL = 2048;              // row totals below this are counted in LDS
+constexpr int COLBITS = 10, VBITS = 8, TBITS = 14;
+constexpr u32 VLIM = 1u << VBITS;      // counts a record can hold: 1 .. 255
+constexpr u32 TLIM = 1u << TBITS;      // row totals a record can hold: 0 .. 16383
+constexpr int BBLOCK = 1024;           // bucket / reduce kernels
+constexpr int IMAGE_LDS_BYTES = 112 * 1024;
+constexpr int WTAB = 2048;             // row totals whose weight 1 / (1 + n) is tabulated in LDS
+constexpr int OVF = 2048;              // slots of an image's overflow table (counts beyond the bins)
+
+struct Plan {
+    int sh, CB, NB, BL, AC, G, W;
+    long long rows_per_wg, max_chunks;
+    long long image_bytes;
+    // workspace offsets (bytes)
+    long long off_head, off_cbucket, off_cfill, off_sorted, off_bstart, off_bcount, off_bpos, off_images, off_chunks, bytes;
+};
+
+inline long long align256(long long x) { return (x + 255) & ~255LL; }
+
+inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan* p) {
+    int sh = 8;
+    while (((K + (1LL << sh) - 1) >> sh) > MAXB) ++sh;
+    if (sh > COLBITS) return false;  // more than 64 buckets of 1024 columns: the first design
+    p->sh = sh;
+    p->CB = 1 << sh;
+    p->NB = (int)((K + p->CB - 1) >> sh);
+    int ac = 4;
+    while (ac > 1 && 8LL * ac * p->CB > 16 * 1024) ac >>= 1;
+    p->AC = ac;
+    long long bl = (IMAGE_LDS_BYTES - 8LL * OVF - 8LL * ac * p->CB) / (4LL * p->CB);
+    if (bl > nbins - 1) bl = nbins - 1;
+    if (bl > (long long)VLIM - 1) bl = VLIM - 1;
+    if (bl < 1) bl = 1;
+    p->BL = (int)bl;
+    p->image_bytes = 8LL * ac * p->CB + 4LL * p->CB * bl + 8LL * OVF;  // a multiple of 16
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    long long G = cus;
+    if (G > (N + PWAVES - 1) / PWAVES) G = (N + PWAVES - 1) / PWAVES;
+    if (G < 1) G = 1;
+    p->G = (int)G;
+    p->rows_per_wg = (N + G - 1) / G;
+    p->W = cus;
+    // every record fills a slot; every (wave, bucket) pair may leave one chunk partly filled
+    p->max_chunks = (nnz + CHUNK - 1) / CHUNK + G * ((long long)PWAVES * p->NB + 2) + 64;
+    if (p->max_chunks >= (1LL << 21)) return false;  // sorted entries hold 21-bit chunk ids
+    long long o = 0;
+    p->off_head = o;     o = align256(o + 256);
+    p->off_cbucket = o;  o = align256(o + p->max_chunks);
+    p->off_cfill = o;    o = align256(o + 2 * p->max_chunks);
+    p->off_sorted = o;   o = align256(o + 4 * p->max_chunks);
+    p->off_bstart = o;   o = align256(o + 4 * (MAXB + 2));
+    p->off_bcount = o;   o = align256(o + 4 * MAXB);
+    p->off_bpos = o;     o = align256(o + 4 * MAXB);
+    p->off_images = o;   o = align256(o + (long long)(p->NB + p->W) * p->image_bytes);
+    p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL);
+    p->bytes = o;
+    return true;
+}
+
+struct PartArgs {
+    const long long* rowptr;
+    const int* colidx;
+    const int* vals;
+    long long N, nnz, K, nbins, tbins, rows_per_wg, max_chunks;
+    int sh, NB, TB;  // TB = min(tbins, TBL)
+    long long chunks_per_wg_extra;  // chunk ids a workgroup owns beyond its entries / CHUNK
+    unsigned char* chunk_bucket;
+    unsigned short* chunk_fill;
+    u32* chunks;
+    u64* hist;
+    u64* histV;
+    double* init_acc;
+    u64* status;
+};
+
+// Per-wave staging in LDS.  All of it is private to one wave: LDS serves a wave's accesses in
+// program order, so no barrier is needed between the phases below, only compiler ordering points.
+//
+// cnt[b] only ever grows: record number p of the (wave, bucket) stream sits in ring slot p mod RING,
+// belongs to unit p / UNIT (16 records = one aligned 64-byte store unit) and to the wave's chunk
+// number p / CHUNK of that bucket, at offset p mod CHUNK.  The lane that stages the LAST record of a
+// unit writes the unit out on the spot (four 16-byte stores from its own lane): no scan over the
+// buckets, no ring bookkeeping.  A step stages at most two units' worth per bucket at a time, so a
+// unit is never overwritten before it has left (see `process`).
+struct WaveStage {
+    u32 ring[MAXB][RING];  // RING = 2 units
+    u32 cnt[MAXB];         // records staged so far (monotone)
+    u32 cptr[MAXB][2];     // chunk ids of the bucket's chunk numbers of even / odd parity
+};
+
+// Compiler-only ordering point (no instruction, in particular no s_waitcnt: a hardware fence here
+// made every staging phase wait for the wave's outstanding global stores and prefetched loads).
+__device__ __forceinline__ void wave_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Chunk number `seq` of (wave, bucket b) begins: take an id from the workgroup's range.  Called by one
+// lane.  Every chunk is recorded as full; the last one of a stream is corrected by the final flush.
+__device__ __forceinline__ u32 open_chunk(WaveStage& st, const PartArgs& a, int b, u32 seq,
+                                          u32* wg_next, long long cbase, long long climit) {
+    // an LDS counter, no global atomic (one pool head for the whole chip saturates at ~90
+    // allocations per microsecond: 4.4 ms for the 385 k chunks of a 4 M-row shard)
+    const long long cl = cbase + (long long)atomicAdd(wg_next, 1u);
+    u32 id = 0xFFFFFFFFu;
+    if (cl < climit) {
+        id = (u32)cl;
+        a.chunk_bucket[id] = (unsigned char)b;
+        a.chunk_fill[id] = (unsigned short)CHUNK;
+    } else {
+        atomicAdd(&a.status[6], 1ULL);  // only overlapping rows of a malformed rowptr get here
+    }
+    st.cptr[b][seq & 1] = id;
+    return id;
+}
+
+__global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    WaveStage* stages = (WaveStage*)lds_raw;
+    u32* tb = (u32*)(lds_raw + sizeof(WaveStage) * PWAVES);  // [TB] row-total bins
+    __shared__ u64 sh_stat[8];
+    __shared__ u32 wg_next;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WaveStage& st = stages[wave];
+    for (int i = tid; i < a.TB; i += PBLOCK) tb[i] = 0;
+    if (tid < 8) sh_stat[tid] = 0;
+    if (tid == 0) wg_next = 0;
+    st.cnt[lane] = 0;
+    st.cptr[lane][0] = 0xFFFFFFFFu;
+    st.cptr[lane][1] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    const long long R0 = (long long)blockIdx.x * a.rows_per_wg;
+    long long R1 = R0 + a.rows_per_wg;
+    if (R1 > a.N) R1 = a.N;
+    const u32 cmask = (1u << a.sh) - 1;
+    const u32 vmax = a.nbins < (long long)VLIM ? (u32)a.nbins : VLIM;  // counts a record and hist hold
+    const u32 tmax = (u32)a.TB < TLIM ? (u32)a.TB : TLIM;              // totals the LDS bins and a record hold
+    u32 maxv = 0;
+    u64 maxt = 0, bad = 0, big = 0, nrows = 0, badrows = 0;
+    bool pool_ok = true;
+    // This workgroup's chunk ids: [cbase, climit).  Its rows hold E = rowptr[R1] - rowptr[R0] entries,
+    // so it needs at most ceil(E / CHUNK) full chunks plus one partly filled chunk per (wave,
+    // bucket); ranges of successive workgroups cannot overlap because
+    // floor((S + E) / CHUNK) - floor(S / CHUNK) >= ceil(E / CHUNK) - 1.  (A malformed rowptr only
+    // shrinks a range: ids are clamped to the pool, and a range that runs out flags status[6].)
+    long long cbase = 0, climit = 0;
+    if (R0 < R1) {
+        const long long s0 = a.rowptr[R0] - a.rowptr[0], s1 = a.rowptr[R1] - a.rowptr[0];
+        cbase = s0 / CHUNK + (long long)blockIdx.x * a.chunks_per_wg_extra;
+        climit = cbase + (s1 > s0 ? (s1 - s0) / CHUNK : 0) + a.chunks_per_wg_extra;
+        if (cbase < 0) cbase = 0;
+        if (climit > a.max_chunks) climit = a.max_chunks;
+        if ((long long)(blockIdx.x + 1) < (long long)gridDim.x) {
+            // never beyond the next workgroup's base
+            const long long nb0 = (a.rowptr[R1] - a.rowptr[0]) / CHUNK + (long long)(blockIdx.x + 1) * a.chunks_per_wg_extra;
+            if (climit > nb0) climit = nb0;
+        }
+    }
+
+    // Stages the records of the lanes with `ok` set (count in 1 .. VLIM - 1 and below nbins, column
+    // below K, row total below TLIM) and writes out the units they complete.
+    auto stage = [&](int c, u32 v, u32 total, bool ok) {
+        const int b = ok ? (c >> a.sh) : 0;
+        const u32 rec = ((u32)c & cmask) | (v << COLBITS) | (total << (COLBITS + VBITS));
+        if (!__any(ok)) return;
+        // every record gets its number in its bucket's stream at once; pos0 = the stream's length
+        // before this step (the same for all lanes of a bucket)
+        u32 pos0 = 0, pos = 0;
+        if (ok) {
+            pos0 = st.cnt[b];
+            wave_fence();
+            pos = atomicAdd(&st.cnt[b], 1u);
+        }
+        wave_fence();
+        // Phase q stages the records of units first + 2q, first + 2q + 1 (first = the unit the
+        // stream stood in): with the ring two units long, a unit is written out before a record two
+        // units later lands on its slots.  One phase unless a bucket takes more than 16 of the
+        // step's records.
+        const u32 rel = (pos >> 4) - (pos0 >> 4);
+        bool pending = ok;
+        for (u32 q = 0; __any(pending); ++q) {
+            const bool now = pending && (rel >> 1) == q;
+            if (now) st.ring[b][pos & (RING - 1)] = rec;
+            wave_fence();
+            const bool owner = now && (pos & (UNIT - 1)) == (u32)(UNIT - 1);  // staged a unit's last record
+            const u32 seq = pos >> 10;                         // chunk number of the stream (CHUNK = 2^10)
+            const u32 off = (pos & (CHUNK - 1)) - (UNIT - 1);  // the unit's offset in its chunk
+            // units that begin a chunk open it first; only then does any lane look a chunk id up
+            // (two units of one bucket can leave in the same phase, the second of them mid-chunk)
+            if (owner && off == 0) open_chunk(st, a, b, seq, &wg_next, cbase, climit);
+            wave_fence();
+            if (owner) {
+                const u32 id = st.cptr[b][seq & 1];
+                if (id != 0xFFFFFFFFu) {
+                    const uint4* src = (const uint4*)&st.ring[b][pos & (RING - 1) & ~(UNIT - 1)];
+                    uint4* dst = (uint4*)(a.chunks + (long long)id * CHUNK + off);
+                    const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+                    dst[0] = x0;
+                    dst[1] = x1;
+                    dst[2] = x2;
+                    dst[3] = x3;
+                }
+            }
+            wave_fence();
+            if (now) pending = false;
+        }
+    };
+
+    // one entry per lane: classify, stage the record, flush full units
+    auto process = [&](int c, int v, u64 total, bool active) {
+        bool ok = active && v != 0;
+        if (ok && (v < 0 || (u32)c >= (u32)a.K)) {
+            bad++;
+            ok = false;
+        }
+        if (ok) maxv = (u32)v > maxv ? (u32)v : maxv;
+        if (ok && (long long)v >= a.nbins) {  // beyond the caller's histogram: reported, not counted
+            big++;                            // (the mean accumulator still takes it, as on the other paths)
+            const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+            atomicAdd(&a.init_acc[c], __dmul_rn((double)v, w));
+            ok = false;
+        }
+        if (ok && ((u32)v >= VLIM || total >= (u64)TLIM)) {  // a record cannot hold it
+            atomicAdd(&a.hist[(long long)c * a.nbins + v], 1ULL);
+            const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+            atomicAdd(&a.init_acc[c], __dmul_rn((double)v, w));
+            ok = false;
+        }
+        stage(c, (u32)v, (u32)total, ok);
+    };
+
+    // Software pipeline over the wave's rows: the entries of the next row and the pointers of the next
+    // 64 rows are in flight while the current row is staged.
+    auto row_ok = [&](long long p0, long long p1) { return p0 >= 0 && p1 >= p0 && p1 <= a.nnz; };
+    auto load_entries = [&](long long p0, long long p1, int& c, int& v) {
+        c = 0;
+        v = 0;
+        if (row_ok(p0, p1) && p1 - p0 <= 64 && lane < p1 - p0) {
+            c = __builtin_nontemporal_load(a.colidx + p0 + lane);
+            v = __builtin_nontemporal_load(a.vals + p0 + lane);
+        }
+    };
+    // Row pointers come 64 rows at a time as VECTOR loads (lane l holds the pointers of the wave's
+    // row 64 j + l) and are handed out by v_readlane.  Scalar loads of them would share the LDS
+    // operations' counter (lgkmcnt, no in-order guarantee): every wait for an LDS result would then
+    // also wait out the memory latency of the pointer prefetch, once per row.
+    const long long nrw = R1 > R0 + wave ? (R1 - R0 - wave + PWAVES - 1) / PWAVES : 0;  // this wave's rows
+    auto load_batch = [&](long long j, long long& P0, long long& P1) {
+        const long long i = j * 64 + lane;
+        P0 = 0;
+        P1 = -1;
+        if (i < nrw) {
+            const long long r = R0 + wave + i * PWAVES;
+            P0 = a.rowptr[r];
+            P1 = a.rowptr[r + 1];
+        }
+    };
+    auto lane_val = [&](long long P, int idx) -> long long {
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)P, idx);
+        const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)((u64)P >> 32), idx);
+        return (long long)((u64)lo | ((u64)hi << 32));
+    };
+    long long C0, C1, N0, N1;
+    load_batch(0, C0, C1);
+    load_batch(1, N0, N1);
+    long long pA0 = 0, pA1 = -1;
+    int cN = 0, vN = 0;
+    if (nrw > 0) {
+        pA0 = lane_val(C0, 0);
+        pA1 = lane_val(C1, 0);
+        load_entries(pA0, pA1, cN, vN);
+    }
+    for (long long i = 0; i < nrw; ++i) {
+        const long long p0 = pA0, p1 = pA1;
+        const int c0 = cN, v0 = vN;
+        const long long ni = i + 1;
+        if ((ni & 63) == 0) {  // wave-uniform: the next batch of pointers becomes current
+            C0 = N0;
+            C1 = N1;
+            load_batch((ni >> 6) + 1, N0, N1);
+        }
+        if (ni < nrw) {
+            const int idx = __builtin_amdgcn_readfirstlane((int)(ni & 63));
+            pA0 = lane_val(C0, idx);
+            pA1 = lane_val(C1, idx);
+            load_entries(pA0, pA1, cN, vN);
+        }
+        // ---- the plain row (nearly all of them): at most 64 entries, every count in 0 .. vmax - 1, every
+        //      column in range, a total the LDS bins and a record hold: one straight path ---------------
+        if (row_ok(p0, p1) && p1 - p0 <= 64) {
+            const bool in = lane < (int)(p1 - p0);
+            const u32 uv = (u32)v0;  // a negative count reads as a huge one
+            if (!__any(in && (uv >= vmax || (u32)c0 >= (u32)a.K))) {
+                const u32 tot = dme_wave_sum_u32(uv);  // lanes beyond the row hold 0; 64 * 255 cannot wrap
+                if (tot < tmax) {
+                    nrows++;
+                    maxv = uv > maxv ? uv : maxv;
+                    if (tot > 0) {
+                        maxt = (u64)tot > maxt ? (u64)tot : maxt;
+                        if (lane == 0) atomicAdd(&tb[tot], 1u);
+                    }
+                    stage(c0, uv, tot, in && uv != 0);
+                    continue;
+                }
+            }
+        }
+        // ---- every other row: the general path ----------------------------------------------------------
+        if (!row_ok(p0, p1)) {  // malformed: the row is not read (wave-uniform)
+            badrows++;
+            continue;
+        }
+        nrows++;
+        const long long len = p1 - p0;
+        // ---- the row total (DE/dme.py:121 sum(row)) ------------------------------------------
+        u64 total = 0;
+        if (len <= 64) {
+            const u32 pos = v0 > 0 ? (u32)v0 : 0u;
+            if (__builtin_expect(!__any(pos >= (1u << 24)), 1)) total = dme_wave_sum_u32(pos);
+            else total = dme_wave_sum_u64((u64)pos);
+        } else {
+            u64 s = 0;
+            for (long long q = p0 + lane; q < p1; q += 64) {
+                const int v = a.vals[q];
+                s += (u64)(v > 0 ? v : 0);
+            }
+            total = dme_wave_sum_u64(s);
+        }
+        if (total > 0) {
+            maxt = total > maxt ? total : maxt;
+            if (lane == 0) {
+                if (total < (u64)a.TB) atomicAdd(&tb[total], 1u);
+                else if ((long long)total < a.tbins) atomicAdd(&a.histV[total], 1ULL);
+                else atomicAdd(&sh_stat[2], 1ULL);
+            }
+        }
+        // ---- the entries -----------------------------------------------------------------------
+        if (len <= 64) {
+            process(c0, v0, total, lane < len);
+        } else {
+            for (long long q0 = p0; q0 < p1; q0 += 64) {
+                const long long q = q0 + lane;
+                const bool in = q < p1;
+                const int c = in ? a.colidx[q] : 0;
+                const int v = in ? a.vals[q] : 0;
+                process(c, v, total, in);
+            }
+        }
+    }
+    // ---- final flush: lane b writes the last, partial unit of bucket b's stream and its chunk's fill ---
+    wave_fence();
+    if (lane < a.NB && pool_ok) {
+        const u32 n = st.cnt[lane];
+        if (n > 0) {
+            const u32 part = n & (UNIT - 1);
+            const u32 seq = (n - 1) >> 10;            // the stream's last chunk
+            u32 id;
+            if (part && (n & (CHUNK - 1)) == part)    // the partial unit opens a chunk of its own
+                id = open_chunk(st, a, lane, seq, &wg_next, cbase, climit);
+            else
+                id = st.cptr[lane][seq & 1];
+            if (id != 0xFFFFFFFFu) {
+                const u32 first = n - part;           // stream number of the unit's first record
+                for (u32 j = 0; j < part; ++j)
+                    a.chunks[(long long)id * CHUNK + ((first + j) & (CHUNK - 1))] =
+                        st.ring[lane][(first + j) & (RING - 1)];
+                a.chunk_fill[id] = (unsigned short)(n - (seq << 10));
+            }
+        }
+    }
+    // ---- statistics of the pass ------------------------------------------------------------------------
+    if (lane == 0) {
+        if (nrows) atomicAdd(&sh_stat[0], nrows);
+        if (badrows) atomicAdd(&sh_stat[6], badrows);
+    }
+    bad = dme_wave_sum_u64(bad);
+    big = dme_wave_sum_u64(big);
+    const u32 mv = dme_wave_max_u32(maxv);
+    if (lane == 0) {
+        if (bad) atomicAdd(&sh_stat[3], bad);
+        if (big) atomicAdd(&sh_stat[1], big);
+        if (mv) atomicMax(&sh_stat[4], (u64)mv);
+        if (maxt) atomicMax(&sh_stat[5], maxt);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.TB; i += PBLOCK) {
+        const u32 cn = tb[i];
+        if (cn) atomicAdd(&a.histV[i], (u64)cn);
+    }
+    if (tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
+    if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
+    if (tid == 6 && sh_stat[6]) atomicAdd(&a.status[6], sh_stat[6]);
+}
+
+// Lists the chunks bucket by bucket (a counting sort over three small launches):
+// sorted[i] = chunk id | (records in the chunk - 1) << IDBITS for the chunks that hold records,
+// bstart[b] = first position of bucket b in `sorted`, bstart[NB] = number of listed chunks.
+constexpr int IDBITS = 21;           // chunk ids below 2^21 (the plan refuses larger pools)
+constexpr int SBLOCK = 256;
+constexpr int SGRID = 128;
+
+__global__ __launch_bounds__(SBLOCK) void csr2_sort_count_kernel(long long max_chunks,
+                                                                 const unsigned char* chunk_bucket,
+                                                                 const unsigned short* chunk_fill,
+                                                                 u32* bcount /*[MAXB], zeroed*/) {
+    __shared__ u32 cnt[MAXB];
+    const int tid = threadIdx.x;
+    if (tid < MAXB) cnt[tid] = 0;
+    __syncthreads();
+    const long long nc = max_chunks;  // ids nobody took have fill 0 (the table is zeroed per call)
+    for (long long c = (long long)blockIdx.x * SBLOCK + tid; c < nc; c += (long long)SGRID * SBLOCK)
+        if (chunk_fill[c] > 0) atomicAdd(&cnt[chunk_bucket[c] & (MAXB - 1)], 1u);
+    __syncthreads();
+    if (tid < MAXB && cnt[tid]) atomicAdd(&bcount[tid], cnt[tid]);
+}
+
+__global__ __launch_bounds__(64) void csr2_sort_scan_kernel(const u32* bcount, int NB, u32* bstart,
+                                                            u32* bpos) {
+    const int lane = threadIdx.x;
+    const u32 x = lane < NB ? bcount[lane] : 0u;
+    u32 inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane < NB) {
+        bstart[lane] = inc - x;
+        bpos[lane] = inc - x;
+    }
+    if (lane == 63) bstart[NB] = inc;
+}
+
+__global__ __launch_bounds__(SBLOCK) void csr2_sort_fill_kernel(long long max_chunks,
+                                                                const unsigned char* chunk_bucket,
+                                                                const unsigned short* chunk_fill,
+                                                                u32* bpos, u32* sorted) {
+    __shared__ u32 cnt[MAXB];
+    __shared__ u32 first[MAXB];
+    const int tid = threadIdx.x;
+    const long long nc = max_chunks;
+    // a workgroup's chunks: the contiguous slice [lo, hi)
+    const long long per = (nc + SGRID - 1) / SGRID;
+    const long long lo = (long long)blockIdx.x * per;
+    long long hi = lo + per;
+    if (hi > nc) hi = nc;
+    if (tid < MAXB) cnt[tid] = 0;
+    __syncthreads();
+    for (long long c = lo + tid; c < hi; c += SBLOCK)
+        if (chunk_fill[c] > 0) atomicAdd(&cnt[chunk_bucket[c] & (MAXB - 1)], 1u);
+    __syncthreads();
+    if (tid < MAXB) {
+        first[tid] = cnt[tid] ? atomicAdd(&bpos[tid], cnt[tid]) : 0u;
+        cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (long long c = lo + tid; c < hi; c += SBLOCK) {
+        const u32 f = chunk_fill[c];
+        if (f > 0) {
+            const int b = chunk_bucket[c] & (MAXB - 1);
+            sorted[first[b] + atomicAdd(&cnt[b], 1u)] = (u32)c | ((f - 1) << IDBITS);
+        }
+    }
+}
+
+struct BucketArgs {
+    const u32* chunks;
+    const u32* sorted;  // chunk id | (fill - 1) << IDBITS
+    const u32* bstart;  // [NB + 1]
+    long long K, nbins;
+    int sh, NB, BL, W, AC;
+    u64* hist;
+    double* init_acc;
+    const u64* status;
+    // [NB + W] LDS images: AC x CB fp64 accumulators, BL x CB counters, then the overflow table
+    // (OVF keys, OVF counts) for counts beyond the bins
+    char* images;
+    long long image_bytes;
+};
+
+__device__ __forceinline__ u32 piece_chunks(u32 total, int W) { return (total + (u32)W - 1) / (u32)W; }
+
+__global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
+    extern __shared__ u64 lds64[];
+    const int CB = 1 << a.sh;
+    double* acc = (double*)lds64;        // [AC][CB]
+    u32* h = (u32*)(acc + a.AC * CB);    // [BL][CB]
+    // Counts beyond the bins belong to a few head-of-vocabulary columns, whose (column, count) cells
+    // repeat: sent to global atomics they pile up on a few addresses, which the memory side serialises
+    // (3.3 ms for 189 M records, most of it waiting on ~1 % of them).  They are counted in a small
+    // open-addressing table of the image instead: key = column-in-bucket << VBITS | count, + 1.
+    u32* okey = h + CB * a.BL;           // [OVF]
+    u32* ocnt = okey + OVF;              // [OVF]
+    // 1 / (1 + n) for row totals below WTAB (DE/fdp.py:88 weightForMean), behind the image: the fp64
+    // division was a third of the pass's vector instructions
+    const double* wtab = (const double*)(ocnt + OVF);
+    for (int n = threadIdx.x; n < WTAB; n += BBLOCK)
+        ((double*)wtab)[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
+    const u32 acmask = (u32)a.AC - 1;
+    const int tid = threadIdx.x;
+    const u32 total = a.bstart[a.NB];
+    const u32 piece = piece_chunks(total, a.W);
+    u32 pos = piece * blockIdx.x;
+    u32 end = pos + piece;
+    if (end > total) end = total;
+    if (pos >= end) return;
+    int b = 0;
+    while (a.bstart[b + 1] <= pos) ++b;  // NB <= 64
+    const int cells = CB * a.BL;
+    const u32 cmask = (1u << COLBITS) - 1;
+    while (pos < end) {
+        u32 seg_end = a.bstart[b + 1];
+        if (seg_end > end) seg_end = end;
+        if (seg_end > pos) {
+            for (int i = tid; i < cells + 2 * OVF; i += BBLOCK) h[i] = 0;  // bins and overflow table
+            for (int i = tid; i < a.AC * CB; i += BBLOCK) acc[i] = 0.0;
+            __syncthreads();
+            const long long kbase = (long long)b << a.sh;
+            auto one = [&](u32 rec) {
+                const u32 v = (rec >> COLBITS) & (VLIM - 1);
+                if (v == 0) return;
+                const u32 cl = rec & cmask;
+                const u32 tot = rec >> (COLBITS + VBITS);
+                if (v <= (u32)a.BL) {
+                    atomicAdd(&h[(v - 1) * CB + cl], 1u);  // bin-major: bank = column
+                } else {
+                    const u32 key = ((cl << VBITS) | v) + 1u;
+                    u32 slot = (key * 2654435761u) >> (32 - 11);  // OVF = 2^11
+                    bool placed = false;
+                    for (int probe = 0; probe < 16 && !placed; ++probe) {
+                        const u32 old = atomicCAS(&okey[slot], 0u, key);
+                        if (old == 0u || old == key) {
+                            atomicAdd(&ocnt[slot], 1u);
+                            placed = true;
+                        }
+                        slot = (slot + 1) & (OVF - 1);
+                    }
+                    if (!placed) atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], 1ULL);  // table crowded
+                }
+                const double w = tot < (u32)WTAB ? wtab[tot] : __ddiv_rn(1.0, __dadd_rn(1.0, (double)tot));
+                __hip_atomic_fetch_add(&acc[((u32)tid & acmask) * CB + cl], __dmul_rn((double)v, w),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            // a chunk is CHUNK = BBLOCK records: one per thread.  Two register buffers of eight chunks:
+            // the loads of the next eight are in flight while the current eight are counted.
+            constexpr int D = 8;
+            auto fetch = [&](u32 ci, u32 (&rec)[D]) {
+                u32 se[D];
+#pragma unroll
+                for (int q = 0; q < D; ++q) se[q] = ci + q < seg_end ? a.sorted[ci + q] : 0u;
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+                    rec[q] = (ci + q < seg_end && (u32)tid <= (se[q] >> IDBITS))
+                                 ? __builtin_nontemporal_load(a.chunks + (long long)(se[q] & ((1u << IDBITS) - 1)) * CHUNK + tid)
+                                 : 0u;
+            };
+            u32 ra[D], rb[D];
+            u32 ci = pos;
+            fetch(ci, ra);
+            while (true) {
+                fetch(ci + D, rb);
+#pragma unroll
+                for (int q = 0; q < D; ++q) one(ra[q]);
+                ci += D;
+                if (ci >= seg_end) break;
+                fetch(ci + D, ra);
+#pragma unroll
+                for (int q = 0; q < D; ++q) one(rb[q]);
+                ci += D;
+                if (ci >= seg_end) break;
+            }
+            __syncthreads();
+            // The run (b, piece) is the (b + piece)-th of the list: runs are ordered and each one
+            // advances b or the piece.  Its LDS image goes out as it is.
+            {
+                uint4* dst = (uint4*)(a.images + (long long)(b + (int)blockIdx.x) * a.image_bytes);
+                const uint4* src = (const uint4*)lds64;
+                const int n16 = (int)(a.image_bytes >> 4);
+                for (int i = tid; i < n16; i += BBLOCK) dst[i] = src[i];
+            }
+            __syncthreads();
+        }
+        pos = seg_end;
+        ++b;
+    }
+}
+
+// hist[k][1..BL] += the counters of every run of bucket b; init_acc[k] += its accumulators.
+// grid (NB, ceil(CB*BL / 1024)).
+__global__ __launch_bounds__(BBLOCK) void csr2_reduce_kernel(BucketArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const u32 s0 = a.bstart[b], s1 = a.bstart[b + 1];
+    if (s1 == s0) return;
+    const int CB = 1 << a.sh;
+    const u32 piece = piece_chunks(a.bstart[a.NB], a.W);
+    const int w_lo = (int)(s0 / piece), w_hi = (int)((s1 - 1) / piece);
+    const long long kbase = (long long)b << a.sh;
+    const int cells = CB * a.BL;
+    const int i = blockIdx.y * BBLOCK + tid;
+    if (i < cells) {
+        u64 sum = 0;
+        const char* img = a.images + 8LL * a.AC * CB + 4LL * i;
+        int w = w_lo;
+        for (; w + 7 <= w_hi; w += 8) {
+            u32 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x[q] = *(const u32*)(img + (long long)(b + w + q) * a.image_bytes);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += x[q];
+        }
+        for (; w <= w_hi; ++w) sum += *(const u32*)(img + (long long)(b + w) * a.image_bytes);
+        if (sum) {
+            const int bin = i / CB + 1, cl = i - (bin - 1) * CB;
+            if (kbase + cl < a.K) a.hist[(kbase + cl) * a.nbins + bin] += sum;
+        }
+    }
+    // the overflow tables of the bucket's runs: block y takes the runs w = w_lo + y, + gridDim.y, ...
+    for (int w = w_lo + (int)blockIdx.y; w <= w_hi; w += (int)gridDim.y) {
+        const u32* okey = (const u32*)(a.images + (long long)(b + w) * a.image_bytes + 8LL * a.AC * CB + 4LL * cells);
+        const u32* ocnt = okey + OVF;
+        for (int sl = tid; sl < OVF; sl += BBLOCK) {
+            const u32 key = okey[sl];
+            if (key) {
+                const u32 cl = (key - 1) >> VBITS, v = (key - 1) & (VLIM - 1);
+                if (kbase + cl < a.K && (long long)v < a.nbins)
+                    atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], (u64)ocnt[sl]);
+            }
+        }
+    }
+    for (int c = tid; c < CB; c += BBLOCK) {
+        double sum = 0.0;
+        for (int w = w_lo + (int)blockIdx.y; w <= w_hi; w += (int)gridDim.y) {
+            const double* img = (const double*)(a.images + (long long)(b + w) * a.image_bytes);
+            for (int q = 0; q < a.AC; ++q) sum = __dadd_rn(sum, img[q * CB + c]);
+        }
+        if (sum != 0.0 && kbase + c < a.K) atomicAdd(&a.init_acc[kbase + c], sum);
+    }
+}
+
+}  // namespace dme_csr2
+
+// Entry points for dme_csr.hip ---------------------------------------------------------------------
+long long dme_csr2_workspace_bytes(long long N, long long nnz, long long K) {
+    dme_csr2::Plan p;
+    if (!dme_csr2::plan(N, nnz, K, 1LL << 30, &p)) return -1;  // the largest LDS image (nbins unknown here)
+    return p.bytes;
+}
+
+// Returns DME_OK, an error, or -1 when the shape is not this design's (more than 65 536 columns).
+int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, long long N, long long nnz,
+                 long long K, u64* hist, long long nbins, u64* histV, long long tbins, double* init_acc,
+                 u64* status, void* workspace, long long workspace_bytes, hipStream_t s) {
+    using namespace dme_csr2;
+    Plan p;
+    if (!plan(N, nnz, K, nbins, &p)) return -1;
+    DME_REQUIRE(workspace_bytes >= p.bytes && ((uintptr_t)workspace & 255) == 0,
+                "CSR workspace: %lld bytes (256-byte aligned) needed, got %lld", p.bytes, workspace_bytes);
+    char* ws = (char*)workspace;
+    PartArgs a{};
+    a.rowptr = rowptr; a.colidx = colidx; a.vals = vals;
+    a.N = N; a.nnz = nnz; a.K = K; a.nbins = nbins; a.tbins = tbins;
+    a.rows_per_wg = p.rows_per_wg; a.max_chunks = p.max_chunks;
+    a.sh = p.sh; a.NB = p.NB;
+    a.TB = (int)(tbins < TBL ? tbins : TBL);
+    a.chunks_per_wg_extra = (long long)PWAVES * p.NB + 2;
+    a.chunk_bucket = (unsigned char*)(ws + p.off_cbucket);
+    a.chunk_fill = (unsigned short*)(ws + p.off_cfill);
+    a.chunks = (u32*)(ws + p.off_chunks);
+    a.hist = hist; a.histV = histV; a.init_acc = init_acc; a.status = status;
+    DME_HIP_CHECK(hipMemsetAsync(a.chunk_fill, 0, 2 * p.max_chunks, s));
+    const size_t lds_part = sizeof(WaveStage) * PWAVES + 4 * (size_t)a.TB;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    DME_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr2_part_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(sizeof(WaveStage) * PWAVES + 4 * TBL)));
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr2_bucket_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          IMAGE_LDS_BYTES + 8 * WTAB));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(csr2_part_kernel, dim3(p.G), dim3(PBLOCK), lds_part, s, a);
+    u32* sorted = (u32*)(ws + p.off_sorted);
+    u32* bstart = (u32*)(ws + p.off_bstart);
+    u32* bcount = (u32*)(ws + p.off_bcount);
+    u32* bpos = (u32*)(ws + p.off_bpos);
+    DME_HIP_CHECK(hipMemsetAsync(bcount, 0, 4 * MAXB, s));
+    hipLaunchKernelGGL(csr2_sort_count_kernel, dim3(SGRID), dim3(SBLOCK), 0, s, p.max_chunks, (const unsigned char*)a.chunk_bucket,
+                       (const unsigned short*)a.chunk_fill, bcount);
+    hipLaunchKernelGGL(csr2_sort_scan_kernel, dim3(1), dim3(64), 0, s, (const u32*)bcount, p.NB, bstart, bpos);
+    hipLaunchKernelGGL(csr2_sort_fill_kernel, dim3(SGRID), dim3(SBLOCK), 0, s, p.max_chunks, (const unsigned char*)a.chunk_bucket,
+                       (const unsigned short*)a.chunk_fill, bpos, sorted);
+    BucketArgs bk{};
+    bk.chunks = a.chunks; bk.sorted = sorted; bk.bstart = bstart;
+    bk.K = K; bk.nbins = nbins; bk.sh = p.sh; bk.NB = p.NB; bk.BL = p.BL; bk.W = p.W; bk.AC = p.AC;
+    bk.hist = hist; bk.init_acc = init_acc; bk.status = status;
+    bk.images = ws + p.off_images;
+    bk.image_bytes = p.image_bytes;
+    hipLaunchKernelGGL(csr2_bucket_kernel, dim3(p.W), dim3(BBLOCK), (size_t)p.image_bytes + 8 * WTAB, s, bk);
+    hipLaunchKernelGGL(csr2_reduce_kernel, dim3(p.NB, (p.CB * p.BL + BBLOCK - 1) / BBLOCK),
+                       dim3(BBLOCK), 0, s, bk);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}

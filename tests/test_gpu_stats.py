@@ -341,7 +341,7 @@ def test_csr_partitioned_row_totals_beyond_lds_bins(oracle):
 
 def test_csr_rowptr_beyond_nnz_is_refused():
     """rowptr that spans more entries than the stated nnz (the partition workspace is sized by nnz):
-    the pass writes nothing and flags it; check() raises."""
+    rows beyond it are not read and are flagged; check() raises."""
     dev = _dev()
     rng = np.random.default_rng(3)
     N, K, per = 4000, 3000, 20
@@ -350,7 +350,8 @@ def test_csr_rowptr_beyond_nnz_is_refused():
     col = torch.from_numpy(rng.integers(0, K, size=nnz).astype(np.int32)).cuda()
     val = torch.ones(nnz, dtype=torch.int32, device="cuda")
     hist, histV, acc, status = _csr_direct_nnz(rowptr, col, val, K, 4, 64, claimed_nnz=nnz // 2)
-    assert int(status[6]) >= 1 and int(hist.sum()) == 0 and int(histV.sum()) == 0
+    assert int(status[6]) >= 1
+    assert int(histV.sum()) == int(status[0]) <= N // 2  # nothing beyond the stated entries was read
     st = dev.DeviceStats(K, 3, 63)
     st.status += status
     with pytest.raises(ValueError, match="spans more entries"):
@@ -360,7 +361,8 @@ def test_csr_rowptr_beyond_nnz_is_refused():
 def test_csr_rowptr_running_backwards_is_refused_on_the_partitioned_path():
     """A non-monotonic rowptr (rows that run backwards) whose last entry still equals nnz: the flat
     count pass and the row-wise scatter pass would disagree about the entries of a slab.  The count
-    kernel checks every slab's row pointers first; nothing is counted, check() raises."""
+    pass checks every row's pointers before it reads the row; such rows are skipped and flagged,
+    check() raises."""
     dev = _dev()
     rng = np.random.default_rng(4)
     N, K, per = 4000, 3000, 20
@@ -372,8 +374,8 @@ def test_csr_rowptr_running_backwards_is_refused_on_the_partitioned_path():
     col = torch.from_numpy(rng.integers(0, K, size=nnz).astype(np.int32)).cuda()
     val = torch.ones(nnz, dtype=torch.int32, device="cuda")
     hist, histV, acc, status = _csr_direct_nnz(rowptr, col, val, K, 4, 64, claimed_nnz=nnz)
-    assert int(status[6]) >= 1 and int(hist.sum()) == 0 and int(histV.sum()) == 0
-    assert float(acc.abs().sum()) == 0.0
+    assert int(status[6]) >= 1
+    assert int(histV.sum()) == int(status[0]) < N
     st = dev.DeviceStats(K, 3, 63)
     st.status += status
     with pytest.raises(ValueError, match="rowptr"):
