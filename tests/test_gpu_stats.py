@@ -593,3 +593,27 @@ def test_bounds_pass_csr():
     _lib.check(_lib.lib().dme_bounds_csr_i32(rp.data_ptr(), vd.data_ptr(), N, nnz, out.data_ptr(),
                                              torch.cuda.current_stream().cuda_stream))
     assert out.cpu().tolist() == [int(pos.max()), int(tot.max())]
+
+
+@pytest.mark.parametrize("K,nhot,dtype", [(1000, 6, "u16"), (1000, 40, "u16"), (1000, 6, "i32"), (16, 3, "u16"),
+                                          (200, 8, "i32")])
+def test_hot_columns_bit_exact_vs_oracle(oracle, K, nhot, dtype):
+    """Counts that routinely exceed the packed LDS bins (a few hot columns hold most of every row, more
+    than one cell per row goes to the 64-bit global atomics of the large-count path): U/V bit-exact.
+    Throughput on such data: benchmarks/hot_columns.py, profiles/r2_summary.md."""
+    dev = _dev()
+    rng = np.random.default_rng(K * 100 + nhot)
+    N, M = 6000, 500
+    alpha = np.full(K, 0.002)
+    hot = rng.choice(K, size=min(nhot, K), replace=False)
+    alpha[hot] = 0.3  # a row's mass sits in one or two of the hot columns
+    tot = rng.integers(1, M + 1, size=N)
+    X = np.stack([rng.multinomial(t, rng.dirichlet(alpha)) for t in tot]).astype(np.int32)
+    assert X.max() > 200
+    st = dev.DeviceStats(K)
+    st.add_dense(_to_dev(X, dtype), max_count=M, max_total=M)
+    info = st.check()
+    assert info["rows"] == N and info["max_count"] == int(X.max())
+    ref = oracle.append_rows(X)
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
