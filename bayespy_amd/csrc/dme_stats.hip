@@ -132,7 +132,11 @@ template <int J, int E, int ES>
 struct StatsCfg {
     // threads per workgroup (one workgroup per CU): 1024 leaves 128 VGPRs per lane, which the
     // 16-column uint16 kernel fits; wider lanes (and int32's 16 columns) take 512 or 256.
-    static constexpr int BLOCK = (J * E >= 64) ? 256 : ((J * E > 16) ? 512 : 1024);
+    // (uint16 rows of 8 vectors per lane - K in 2049..4096 - fit 512 threads at 236 VGPRs: eight waves
+    // per CU instead of four took K = 4096 from 3.28 to 5.79 TB/s; the packed int32 kernel of the same
+    // width spills there and keeps 256)
+    static constexpr int BLOCK =
+        (J * E > 64 || (ES == 4 && J * E >= 64)) ? 256 : ((J * E > 16) ? 512 : 1024);
     // row groups per register buffer (two buffers): enough 16-byte loads in flight per CU
     // (ES == 4 with E == 8 is the packed-int32 kernel: its raw buffers are twice the size)
     static constexpr int RB = (ES == 4 && E == 8) ? 1 : ((J == 1) ? DME_RB1 : ((J == 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1)));
@@ -748,7 +752,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.CW = CW;
     p.BRW = p.J * PW * CW;
     const int JE = p.J * E;
-    p.block = (JE >= 64) ? 256 : ((JE > 16) ? 512 : 1024);
+    p.block = (JE > 64 || (elem_bytes == 4 && JE >= 64)) ? 256 : ((JE > 16) ? 512 : 1024);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
