@@ -28,6 +28,7 @@ SIGNATURES = {
     "dme_last_error": (ctypes.c_char_p, []),
     "dme_device_cus": (_int, []),
     "dme_stats_workspace_bytes": (_i64, [_i64, _i64]),
+    "dme_stats_staging_bytes": (_i64, [_vp, _i64, _i64, _i64, _int]),
     "dme_stats_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dme_stats_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dme_bounds_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),

@@ -128,18 +128,29 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
     return __builtin_bit_cast(u32, __builtin_elementwise_max(x, y));
 }
 
-template <int J, int E, int ES>
+// Threads per workgroup (one workgroup per CU) and row groups per register buffer, for J vectors of
+// E elements of ES bytes per lane; the kernel and the host plan both take them from here.
+//   threads: 1024 leaves 128 VGPRs per lane, which the 16-column uint16 kernel fits; wider lanes (and
+//     int32's 16 columns) take 512 or 256.  uint16 rows of up to 8 vectors per lane fit 512 threads
+//     (236 VGPRs at J = 8): eight waves per CU instead of four took K = 4096 from 3.28 to 5.79 TB/s;
+//     the packed int32 kernel of that width spills there and keeps 256.
+//   row groups: enough 16-byte loads in flight per CU (ES == 4 with E == 8 is the packed-int32 kernel:
+//     its raw buffers are twice the size).
+//   teams (TW > 1 waves share a row, see the kernel): 512 threads, one row group per buffer.
+constexpr int stats_block(int J, int E, int ES, int TW = 1) {
+    return TW > 1 ? ((J * E > 16) ? 512 : 1024)
+           : (J * E > 64 || (ES == 4 && J * E > 32)) ? 256 : ((J * E > 16) ? 512 : 1024);
+}
+constexpr int stats_rb(int J, int E, int ES, int TW = 1) {
+    return (TW > 1 || (ES == 4 && E == 8)) ? 1
+           : (J == 1)          ? DME_RB1
+           : (J == 2)          ? 2
+           : ((J == 3 || J == 4) && stats_block(J, E, ES) == 512) ? 2 : 1;
+}
+template <int J, int E, int ES, int TW = 1>
 struct StatsCfg {
-    // threads per workgroup (one workgroup per CU): 1024 leaves 128 VGPRs per lane, which the
-    // 16-column uint16 kernel fits; wider lanes (and int32's 16 columns) take 512 or 256.
-    // (uint16 rows of 8 vectors per lane - K in 2049..4096 - fit 512 threads at 236 VGPRs: eight waves
-    // per CU instead of four took K = 4096 from 3.28 to 5.79 TB/s; the packed int32 kernel of the same
-    // width spills there and keeps 256)
-    static constexpr int BLOCK =
-        (J * E > 64 || (ES == 4 && J * E >= 64)) ? 256 : ((J * E > 16) ? 512 : 1024);
-    // row groups per register buffer (two buffers): enough 16-byte loads in flight per CU
-    // (ES == 4 with E == 8 is the packed-int32 kernel: its raw buffers are twice the size)
-    static constexpr int RB = (ES == 4 && E == 8) ? 1 : ((J == 1) ? DME_RB1 : ((J == 2) ? 2 : ((J == 4 && BLOCK == 512) ? 2 : 1)));
+    static constexpr int BLOCK = stats_block(J, E, ES, TW);
+    static constexpr int RB = stats_rb(J, E, ES, TW);
 };
 
 // T: element type (unsigned short | int).  E: elements per vector (chunk).  J: vectors per lane
@@ -148,22 +159,30 @@ struct StatsCfg {
 // is loaded as two 16-byte vectors, the exceptions (and negatives) are settled one by one, and the
 // eight counts are packed into four dwords that then take the uint16 code - the int32 kernel pays
 // per element what the uint16 kernel pays (~half the instructions of the plain int32 path).
-template <typename T, int E, int J, bool MULTI, bool PACK>
-__global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
+// TW: waves that share a row (a team).  Rows of more than 8 vectors per lane (4 for the packed
+// int32 kernel, whose fp64 accumulators and raw buffers fill the register file) are split over TW
+// waves: wave t of a team takes the vectors 64 * (t + TW * j) + lane, the waves' partial row totals
+// meet in LDS (a counter per team, two sets of slots), everything else is per wave as before.  The LDS image keeps its layout (vector index t + TW * j where a one-wave row has j).
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW>
+__global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
+    static_assert(TW == 1 || !MULTI, "teams are for long rows");
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
     constexpr bool IS16 = RAW16 || PACK;    // the cells are processed as packed 16-bit counts
     constexpr int BYTES = E * (int)sizeof(T);
     constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
     constexpr int NDP = IS16 ? (E >= 2 ? E / 2 : 1) : ND;  // dwords per vector once packed
     constexpr int PW = E >= 2 ? E / 2 : 1;          // LDS words per vector (2 columns per word)
-    constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T)>::BLOCK;
+    constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK;
     constexpr int W = BLOCK / 64;
-    constexpr int RB = StatsCfg<J, E, (int)sizeof(T)>::RB;
+    constexpr int WR = W / TW;  // rows a workgroup has in hand per register-buffer slot
+    constexpr int RB = StatsCfg<J, E, (int)sizeof(T), TW>::RB;
     typedef typename std::conditional<RAW16, u32, u64>::type SumT;
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw = TW > 1 ? wave % TW : 0;    // this wave's place in its team
+    const int wrow = TW > 1 ? wave / TW : wave;  // the team's (= the row's) place in the workgroup
     const int C = a.C;
     const int R = MULTI ? a.R : 1;
     const int r = MULTI ? lane / C : 0;
@@ -179,6 +198,14 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     const u32 vcopy = MULTI ? (u32)((r & (a.VC - 1)) * a.TBpad) : 0u;  // this row slot's copy of the bins
     const int nwords = (int)a.part_words;  // TB + (B+1)*BRW rounded up to a multiple of 4
     for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
+    // Data-error counters and the maxima seen by the rare global-atomic paths live in LDS, not in
+    // registers (the maxima of the LDS-privatised bins are taken by hist_reduce_kernel):
+    // [1] cells >= nbins, [2] rows >= tbins, [3] negative cells, [4] max count, [5] max row total.
+    __shared__ u64 sh_stat[8];
+    __shared__ u64 sh_tot[2][TW > 1 ? W : 1][RB];  // teams: the waves' partial row totals
+    __shared__ u32 sh_team[TW > 1 ? WR : 1];        // teams: parts published so far
+    if (tid < 8) sh_stat[tid] = 0;
+    if (tid < (TW > 1 ? WR : 1)) sh_team[tid] = 0;
     __syncthreads();
     // weightForMean = 1.0 / (1.0 + sumData) (DE/fdp.py:88), tabulated once per workgroup
     for (int n = tid; n < WT; n += BLOCK)
@@ -190,11 +217,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     for (int j = 0; j < J; ++j)
 #pragma unroll
         for (int e = 0; e < E; ++e) acc[j][e] = 0.0;
-    // Data-error counters and the maxima seen by the rare global-atomic paths live in LDS, not in
-    // registers (the maxima of the LDS-privatised bins are taken by hist_reduce_kernel):
-    // [1] cells >= nbins, [2] rows >= tbins, [3] negative cells, [4] max count, [5] max row total.
-    __shared__ u64 sh_stat[8];
-    if (tid < 8) sh_stat[tid] = 0;
+    u32 team_target = 0;
     const u32 Bpk = (u32)a.B | ((u32)a.B << 16);
 
     // Row mapping.  A loop step retires a tile of S = W * RB adjacent row groups; a wave takes RB
@@ -212,7 +235,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     //    adjacent rows in one wave halve those double fetches (K = 1000: 3.32 -> 3.25 ms).  With
     //    line-aligned rows there is nothing to save and the strided order measured 1-4 % faster
     //    (profiles/r1_notes.md).
-    constexpr long long S = (long long)W * RB;  // row groups a workgroup retires per loop step
+    constexpr long long S = (long long)WR * RB;  // row groups a workgroup retires per loop step
     // (the packed int32 kernel sits at its 128-register limit and measured 1-2 % slower
     // interleaved: it keeps the slabs)
     const bool inter = !PACK && a.steps > 0;
@@ -227,7 +250,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     const long long tile0 = inter ? (long long)blockIdx.x * S : 0;
     int goff[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) goff[rb] = adjacent ? wave * RB + rb : rb * W + wave;
+    for (int rb = 0; rb < RB; ++rb) goff[rb] = adjacent ? wrow * RB + rb : rb * WR + wrow;
     const u32 binRowBytes = (u32)BRW * 4u;
     // byte offset of this lane's word 0 inside a bin row; word (j, p) is (j*PW + p)*CW words on.
     // Many side-by-side rows (a.CW == 64: 16 or more per wave) keep a word per LANE, not per column
@@ -235,7 +258,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
     // same-address LDS atomics serialise (K = 16: 1.25 -> 0.89 ms for 4 GB; hist_reduce_kernel adds
     // the row slots' words of a column together).  With few rows per wave the narrower layout
     // measured 1 % faster.
-    const u32 laneWordByte = (u32)((MULTI && CW == 64) ? lane : c) * 4u;
+    const u32 laneWordByte = (u32)((MULTI && CW == 64) ? lane : c) * 4u + (u32)(tw * PW * CW) * 4u;
     char* ldsHb = (char*)ldsH;
     const T* Xp = (const T*)a.X;
     const long long nbins = a.nbins, tbins = a.tbins;
@@ -252,7 +275,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             const bool ok = lane_has_row && (rowi < row1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int chunk = c + 64 * j;
+                const int chunk = c + 64 * (tw + TW * j);
                 if (ok && chunk < C) {
                     load_chunk<BYTES, ND>(Xp + rowi * a.ld + (long long)chunk * E, b.d[rb][j]);
                 } else {
@@ -263,7 +286,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
         }
     };
 
-    auto process_buf = [&](Buf& b, long long tile) {
+    auto process_buf = [&](Buf& b, long long tile, int parity) {
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
 #pragma unroll
@@ -336,6 +359,46 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                 }
             }
         }
+        if constexpr (TW > 1) {
+            // The team's waves add their parts.  No workgroup barrier: that would march all the
+            // waves of the CU in step (every wave waiting for memory at once, then every wave at
+            // the LDS at once; K = 4096 int32: 1.81 ms against 1.50 ms with free-running teams), so a team meets on
+            // a counter of its own.  A wave's LDS operations execute in the order it issues them:
+            // the slots are written before the counter is raised, and a mate that has seen the
+            // count reads the slots after.  Two sets of slots: a wave can be one step ahead of its
+            // mates and no more.  Every wave of a team runs the same nsteps steps, so each wait
+            // ends.  (Relaxed atomics and compiler barriers only: a release / acquire pair here
+            // would also wait for the global loads in flight.)
+            // When the team is the whole workgroup (WR == 1) the barrier is the cheaper meeting
+            // (K = 16384 int32: 1.93 ms against 3.15 ms with the counter).
+            if constexpr (WR > 1) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) sh_tot[parity][wave][rb] = (u64)tot[rb];
+                    asm volatile("" ::: "memory");
+                    __hip_atomic_fetch_add(&sh_team[wrow], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                team_target += TW;
+                while (__hip_atomic_load(&sh_team[wrow], __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) < team_target)
+                    __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+            } else {
+                if (lane == 0) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) sh_tot[parity][wave][rb] = (u64)tot[rb];
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                u64 t = 0;
+#pragma unroll
+                for (int i = 0; i < TW; ++i) t += sh_tot[parity][wrow * TW + i][rb];
+                tot[rb] = (SumT)t;
+            }
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const long long pg = tile + goff[rb];
@@ -362,10 +425,10 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             } else {
                 // ---- row-total histogram: `total` is wave-uniform, so these are scalar branches --
                 if ((u64)total < (u64)TB) {
-                    if (lane == 0 && total > 0 && !DBG(8)) atomicAdd(&ldsV[(u32)total], 1u);
+                    if (lane == 0 && tw == 0 && total > 0 && !DBG(8)) atomicAdd(&ldsV[(u32)total], 1u);
                 } else if (!DBG(8)) {
                     atomicMax(&sh_stat[5], (u64)total);
-                    if (lane == 0) {
+                    if (lane == 0 && tw == 0) {
                         if ((long long)total < tbins) atomicAdd(&a.histV[total], 1ULL);
                         else atomicAdd(&sh_stat[2], 1ULL);
                     }
@@ -376,7 +439,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             // ---- cells --------------------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int chunk = c + 64 * j;
+                const int chunk = c + 64 * (tw + TW * j);
                 if constexpr (IS16) {
                     u32 dwl[NDP];
                     if constexpr (PACK) {
@@ -447,7 +510,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                                 const int q = q0 + t;
                                 const u32 dw = dwl[q];
                                 const u32 lo = dw & 0xffffu;
-                                const u32 wb = laneWordByte + (u32)((j * PW + q) * CW) * 4u;
+                                const u32 wb = laneWordByte + (u32)((j * TW * PW + q) * CW) * 4u;
                                 if (!DBG(1))
                                     atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb)), 1u);
                                 if (!DBG(2)) acc[j][2 * q] = mean_add(acc[j][2 * q], (double)lo, w);
@@ -496,7 +559,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
                         const u32 v0 = b.d[rb][j][e];
                         const u32 v1 = EP == 2 ? b.d[rb][j][e + (EP - 1)] : 0u;
                         if (__builtin_expect((v0 | v1) != 0, 1)) {
-                            const u32 wb = laneWordByte + (u32)((j * PW + (e >> 1)) * CW) * 4u;
+                            const u32 wb = laneWordByte + (u32)((j * TW * PW + (e >> 1)) * CW) * 4u;
                             if (!DBG(1)) atomicAdd((u32*)(ldsHb + (__umul24(v0, binRowBytes) + wb)), 1u);
                             if (!DBG(2)) acc[j][e] = mean_add(acc[j][e], (double)v0, w);
                             if constexpr (EP == 2) {
@@ -522,11 +585,11 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
             load_buf(bufA, tile);
             while (true) {
                 load_buf(bufB, tile + tile_pitch);
-                process_buf(bufA, tile);
+                process_buf(bufA, tile, 0);
                 tile += tile_pitch;
                 if (++k >= nsteps) break;
                 load_buf(bufA, tile + tile_pitch);
-                process_buf(bufB, tile);
+                process_buf(bufB, tile, 1);
                 tile += tile_pitch;
                 if (++k >= nsteps) break;
             }
@@ -552,15 +615,27 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T)>::BLOCK)) void stats
 #pragma unroll
         for (int e = 0; e < E; ++e) ldsD[tid * E + e] = acc[j][e];
         __syncthreads();
-        for (int t = tid; t < CC * E; t += BLOCK) {
+        for (int t = tid; t < CC * TW * E; t += BLOCK) {
             const int cc = t / E, e = t - cc * E;
-            const int chunk = MULTI ? cc : cc + 64 * j;
-            if (chunk < C) {
-                double sum = 0.0;
-                for (int w = 0; w < W; ++w)
-                    for (int rr = 0; rr < R; ++rr)
-                        sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + e]);
-                a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
+            if constexpr (TW > 1) {
+                // cc = 64 * (place in the team) + lane: the sum runs over the teams of the workgroup
+                const int ti = cc >> 6, ln = cc & 63;
+                const int chunk = ln + 64 * (ti + TW * j);
+                if (chunk < C && (long long)chunk * E + e < a.K) {
+                    double sum = 0.0;
+                    for (int w = 0; w < WR; ++w)
+                        sum = __dadd_rn(sum, ldsD[((w * TW + ti) * 64 + ln) * E + e]);
+                    a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
+                }
+            } else {
+                const int chunk = MULTI ? cc : cc + 64 * j;
+                if (chunk < C && (long long)chunk * E + e < a.K) {
+                    double sum = 0.0;
+                    for (int w = 0; w < W; ++w)
+                        for (int rr = 0; rr < R; ++rr)
+                            sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + e]);
+                    a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
+                }
             }
         }
     }
@@ -704,44 +779,64 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
 }
 
 constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
-constexpr int kMaxJ = 8;
+constexpr int kMaxJ = 8;      // vectors per lane and row
+constexpr int kMaxJPack = 2;  // the same for the packed int32 kernel inside a team
 constexpr long long kRowsPerWgMax = 60000;
 
 struct Plan {
-    int E, J, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw;
+    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
 };
 
+// `padded`: the caller's rows are 16-byte aligned, their pitch covers K rounded up to 8 columns and
+// the columns from K on hold zeros (dme_stats_dense_*'s own staging copy, see stats_dense_staged):
+// the vectors may then run past K.
 int plan_dense(int elem_bytes, const void* X, long long N, long long K, long long ld,
-               long long nbins, long long tbins, Plan* pl) {
+               long long nbins, long long tbins, bool padded, Plan* pl) {
     int E = 16 / elem_bytes;
     const uintptr_t addr = (uintptr_t)X;
-    while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
     if (addr % elem_bytes) return dme_set_error(DME_ERR_INVALID_ARG, "X is not element-aligned");
+    if (padded) {
+        if (addr % 16 || (ld * elem_bytes) % 16 || ld < ((K + 7) & ~7LL))
+            return dme_set_error(DME_ERR_INTERNAL, "staged rows: bad pitch");
+    } else {
+        while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
+    }
     // int32 rows of 16-byte-aligned chunks of 8 columns, at least one chunk per lane
-    const bool pack = elem_bytes == 4 && E == 4 && K % 8 == 0 && K / 8 >= 64;
+    const bool pack = elem_bytes == 4 && E == 4 && (padded || K % 8 == 0) && (K + 7) / 8 >= 64;
     if (pack) E = 8;
-    const long long C = K / E;
+    const long long C = (K + E - 1) / E;
     Plan p{};
     p.pack = pack;
     p.E = E;
     p.C = (int)C;
+    p.TW = 1;
     p.multi = C < 64;
+    // vectors per lane that one wave takes; longer rows go to teams of 2, 4 or 8 waves (full
+    // vectors of 8 columns only: other layouts are staged first)
+    const int jmax = pack ? kMaxJPack : kMaxJ;
+    const long long jtot = (C + 63) / 64;
     if (p.multi) {
         p.J = 1;
         p.R = (int)(64 / C);
+    } else if (jtot > jmax && E == 8 && jtot <= (pack ? 16LL : 8LL) * jmax) {
+        int TW = 2;
+        while (TW * (long long)jmax < jtot) TW *= 2;
+        p.TW = TW;
+        p.J = (int)((jtot + TW - 1) / TW);
+        if (p.J <= jmax / 2) p.J = jmax / 2 + 1;  // the team kernels exist for the upper half of J
+        p.R = 1;
     } else {
-        long long j = (C + 63) / 64;
-        int J = 1;
-        while (J < j) J <<= 1;
-        if (J > kMaxJ)
+        // any number of vectors per lane up to kMaxJ (K = 3000 uint16: 6, not 8 with a quarter of the
+        // lanes' loads empty)
+        if (jtot > kMaxJ)
             return dme_set_error(DME_ERR_UNSUPPORTED,
-                                 "dense stats: K=%lld with %d-element vectors needs %lld vectors per "
-                                 "lane (max %d); pad K / align rows to 16 bytes, or use the CSR entry",
-                                 K, E, j, kMaxJ);
-        p.J = J;
+                                 "dense stats: K=%lld in %d-element vectors needs %lld vectors per "
+                                 "lane (at most %d, or %d of 8 elements): use the CSR entry",
+                                 K, E, jtot, kMaxJ, (pack ? 16 : 8) * jmax);
+        p.J = (int)jtot;
         p.R = 1;
     }
     const int PW = E >= 2 ? E / 2 : 1;
@@ -750,9 +845,8 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const bool many_rows = N >= 4000000;
     const int CW = (p.multi && (p.R < 16 || !many_rows)) ? (int)C : 64;
     p.CW = CW;
-    p.BRW = p.J * PW * CW;
-    const int JE = p.J * E;
-    p.block = (JE > 64 || (elem_bytes == 4 && JE >= 64)) ? 256 : ((JE > 16) ? 512 : 1024);
+    p.BRW = p.J * p.TW * PW * CW;
+    p.block = stats_block(p.J, E, elem_bytes, p.TW);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
@@ -798,8 +892,8 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // register-buffer depth), steps = ceil(groups / (grid * S)); a workgroup still counts at most
     // 65535 rows
     {
-        const int W = p.block / 64;
-        const int RB = (elem_bytes == 4 && E == 8) ? 1 : ((p.J == 1) ? DME_RB1 : ((p.J == 2) ? 2 : ((p.J == 4 && p.block == 512) ? 2 : 1)));
+        const int W = p.block / 64 / p.TW;
+        const int RB = stats_rb(p.J, E, elem_bytes, p.TW);
         const long long S = (long long)W * RB;
         const long long groups = (N + p.R - 1) / p.R;
         long long steps = (groups + grid * S - 1) / (grid * S);
@@ -816,9 +910,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     return DME_OK;
 }
 
-template <typename T, int E, int J, bool MULTI, bool PACK = false>
+template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK>;
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
     static bool attr_set[64] = {};
     int dev = 0;
@@ -839,24 +933,40 @@ int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
     switch (p.J) {
         case 1: return launch_dense<T, E, 1, false>(a, p, s);
         case 2: return launch_dense<T, E, 2, false>(a, p, s);
+        case 3: return launch_dense<T, E, 3, false>(a, p, s);
         case 4: return launch_dense<T, E, 4, false>(a, p, s);
+        case 5: return launch_dense<T, E, 5, false>(a, p, s);
+        case 6: return launch_dense<T, E, 6, false>(a, p, s);
+        case 7: return launch_dense<T, E, 7, false>(a, p, s);
         case 8: return launch_dense<T, E, 8, false>(a, p, s);
     }
     return dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
 }
 
+// rows split over teams of TW waves: full vectors of 8 columns, the upper half of J
+template <typename T, bool PACK, int TW>
+int dispatch_team(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    if constexpr (PACK) {
+        switch (p.J) {
+            case 2: return launch_dense<T, 8, 2, false, true, TW>(a, p, s);
+        }
+    } else if constexpr (sizeof(T) == 2) {
+        switch (p.J) {
+            case 5: return launch_dense<T, 8, 5, false, false, TW>(a, p, s);
+            case 6: return launch_dense<T, 8, 6, false, false, TW>(a, p, s);
+            case 7: return launch_dense<T, 8, 7, false, false, TW>(a, p, s);
+            case 8: return launch_dense<T, 8, 8, false, false, TW>(a, p, s);
+        }
+    }
+    return dme_set_error(DME_ERR_INTERNAL, "bad team J=%d", p.J);
+}
+
 template <typename T>
-int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
-                u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
-                long long workspace_bytes, void* stream) {
-    DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", N, K, ld);
-    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
-    DME_REQUIRE(hist && histV && init_acc && status, "null output pointer");
-    DME_REQUIRE(K * nbins < (1LL << 40), "hist too large");
-    if (N == 0) return DME_OK;
-    DME_REQUIRE(X != nullptr, "X is null");
+int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
+                    u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
+                    long long workspace_bytes, void* stream, bool padded) {
     Plan p;
-    int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, &p);
+    int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, padded, &p);
     if (rc) return rc;
     const long long init_bytes = (p.grid * K * 8 + 255) & ~255LL;
     const long long need = init_bytes + p.grid * p.part_words * 4;
@@ -869,18 +979,34 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
                 p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
-    if constexpr (sizeof(T) == 4) {
+    if (p.TW > 1) {
+        if constexpr (sizeof(T) == 4) {
+            if (!p.pack) return dme_set_error(DME_ERR_INTERNAL, "team without packing");
+            switch (p.TW) {
+                case 2: rc = dispatch_team<T, true, 2>(a, p, s); break;
+                case 4: rc = dispatch_team<T, true, 4>(a, p, s); break;
+                case 8: rc = dispatch_team<T, true, 8>(a, p, s); break;
+                case 16: rc = dispatch_team<T, true, 16>(a, p, s); break;
+                default: rc = dme_set_error(DME_ERR_INTERNAL, "bad TW=%d", p.TW);
+            }
+        } else {
+            switch (p.TW) {
+                case 2: rc = dispatch_team<T, false, 2>(a, p, s); break;
+                case 4: rc = dispatch_team<T, false, 4>(a, p, s); break;
+                case 8: rc = dispatch_team<T, false, 8>(a, p, s); break;
+                default: rc = dme_set_error(DME_ERR_INTERNAL, "bad TW=%d", p.TW);
+            }
+        }
+    } else if constexpr (sizeof(T) == 4) {
         if (p.pack) {
             switch (p.J) {
                 case 1: rc = launch_dense<T, 8, 1, false, true>(a, p, s); break;
                 case 2: rc = launch_dense<T, 8, 2, false, true>(a, p, s); break;
-                case 4: rc = launch_dense<T, 8, 4, false, true>(a, p, s); break;
-                case 8: rc = launch_dense<T, 8, 8, false, true>(a, p, s); break;
                 default: rc = dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
             }
         }
     }
-    if (!p.pack) switch (p.E) {
+    if (!p.pack && p.TW == 1) switch (p.E) {
         case 1: rc = dispatch_j<T, 1>(a, p, s); break;
         case 2: rc = dispatch_j<T, 2>(a, p, s); break;
         case 4: rc = dispatch_j<T, 4>(a, p, s); break;
@@ -892,6 +1018,7 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     }
     if (rc) return rc;
     const int PW = p.E >= 2 ? p.E / 2 : 1;
+    // (a team's image reads like a one-wave row's of TW * J vectors per lane)
     ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
                   p.multi ? 1 : 0};
@@ -905,15 +1032,95 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     return DME_OK;
 }
 
-}  // namespace
-
-extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
+long long base_workspace_bytes(long long N, long long K) {
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
     long long rounds = (N + (long long)cus * kRowsPerWgMax - 1) / ((long long)cus * kRowsPerWgMax);
     if (rounds < 1) rounds = 1;
     // per workgroup: K fp64 mean accumulators + one raw LDS histogram image
-    return (int64_t)((long long)cus * rounds * (K * 8 + kLdsBudgetBytes + 64) + 1024);
+    return ((long long)cus * rounds * (K * 8 + kLdsBudgetBytes + 64) + 1024 + 255) & ~255LL;
+}
+
+constexpr long long kStageBytes = 256LL << 20;  // rows staged per round, at most
+constexpr long long kStageMinRows = 4096;
+
+// Layouts the vector loads cannot take as they lie (rows that are not 16-byte aligned, K not a
+// multiple of the vector) with more columns than the narrow-vector kernels hold: the rows are copied,
+// a block at a time, into a 16-byte-aligned staging area behind the workspace whose pitch is K
+// rounded up to 8 columns (the pad columns zeroed), and the block runs as full vectors.  One extra
+// read and write of X; hipMemcpy2DAsync does the copy, nothing is allocated.
+template <typename T>
+int stats_dense_staged(const T* X, long long N, long long K, long long ld, u64* hist,
+                       long long nbins, u64* histV, long long tbins, double* init_acc, u64* status,
+                       void* workspace, long long workspace_bytes, void* stream) {
+    const long long Kp = (K + 7) & ~7LL;
+    const long long row_bytes = Kp * (long long)sizeof(T);
+    const long long base = base_workspace_bytes(N, Kp);
+    long long rows = (workspace_bytes - base) / row_bytes;
+    if (rows > N) rows = N;
+    const long long want = N < kStageMinRows ? N : kStageMinRows;
+    if (!workspace || workspace_bytes < base || rows < want)
+        return dme_set_error(DME_ERR_WORKSPACE,
+                             "stats workspace: this layout (K=%lld, pitch %lld) is staged: need "
+                             "dme_stats_workspace_bytes + dme_stats_staging_bytes, got %lld bytes",
+                             K, ld, workspace_bytes);
+    DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
+    char* stage = (char*)workspace + base;
+    hipStream_t s = (hipStream_t)stream;
+    for (long long r0 = 0; r0 < N; r0 += rows) {
+        const long long nb = N - r0 < rows ? N - r0 : rows;
+        if (Kp > K)
+            DME_HIP_CHECK(hipMemset2DAsync(stage + K * sizeof(T), (size_t)row_bytes, 0,
+                                           (size_t)((Kp - K) * sizeof(T)), (size_t)nb, s));
+        DME_HIP_CHECK(hipMemcpy2DAsync(stage, (size_t)row_bytes, X + r0 * ld, (size_t)(ld * sizeof(T)),
+                                       (size_t)(K * sizeof(T)), (size_t)nb, hipMemcpyDeviceToDevice, s));
+        int rc = stats_dense_run<T>((const T*)stage, nb, K, Kp, hist, nbins, histV, tbins, init_acc,
+                                    status, workspace, base, stream, true);
+        if (rc) return rc;
+    }
+    return DME_OK;
+}
+
+// whether the rows have to be staged: the plan as they lie is refused, the staged one is not
+bool needs_staging(int elem_bytes, const void* X, long long N, long long K, long long ld) {
+    Plan p;
+    if (plan_dense(elem_bytes, X, N, K, ld, 2, 2, false, &p) == DME_OK) return false;
+    const long long jtot = (((K + 7) / 8) + 63) / 64;
+    return jtot <= (elem_bytes == 4 ? 16LL * kMaxJPack : 8LL * kMaxJ);
+}
+
+template <typename T>
+int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
+                u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
+                long long workspace_bytes, void* stream) {
+    DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", N, K, ld);
+    DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
+    DME_REQUIRE(hist && histV && init_acc && status, "null output pointer");
+    DME_REQUIRE(K * nbins < (1LL << 40), "hist too large");
+    if (N == 0) return DME_OK;
+    DME_REQUIRE(X != nullptr, "X is null");
+    if (needs_staging((int)sizeof(T), X, N, K, ld))
+        return stats_dense_staged<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status,
+                                     workspace, workspace_bytes, stream);
+    return stats_dense_run<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status, workspace,
+                              workspace_bytes, stream, false);
+}
+
+}  // namespace
+
+extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
+    return (int64_t)base_workspace_bytes(N, (K + 7) & ~7LL);
+}
+
+extern "C" int64_t dme_stats_staging_bytes(const void* X, int64_t N, int64_t K, int64_t ld,
+                                           int elem_bytes) {
+    if ((elem_bytes != 2 && elem_bytes != 4) || N <= 0 || K < 1 || ld < K) return 0;
+    if (!needs_staging(elem_bytes, X, N, K, ld)) return 0;
+    const long long row_bytes = ((K + 7) & ~7LL) * elem_bytes;
+    long long rows = kStageBytes / row_bytes;
+    if (rows < kStageMinRows) rows = kStageMinRows;
+    if (rows > N) rows = N;
+    return (int64_t)(rows * row_bytes);
 }
 
 extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,

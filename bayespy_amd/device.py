@@ -288,9 +288,13 @@ class DeviceStats:
             new[:self.tbins] = self.histV
             self.histV, self.tbins = new, tb
 
-    def _workspace(self, N):
+    def _workspace(self, N, X=None):
         need = _lib.lib().dme_stats_workspace_bytes(int(N), self.K) + 256
+        if X is not None:  # layouts that the library stages first (odd pitch with many columns)
+            need += _lib.lib().dme_stats_staging_bytes(X.data_ptr(), X.shape[0], self.K,
+                                                       X.stride(0), X.element_size())
         if self._ws is None or self._ws.numel() < need:
+            self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         off = (-self._ws.data_ptr()) % 256
         return self._ws.data_ptr() + off, self._ws.numel() - off
@@ -330,54 +334,12 @@ class DeviceStats:
             max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
         with _on(self.device):
-            ws, wsb = self._workspace(X.shape[0])
-            rc = fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
-                    self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
-                    _ptr(self.status), ws, wsb, _stream())
-            if rc == _lib.ERR_UNSUPPORTED:
-                return self._add_dense_repacked(X, max_count, max_total)
-            _lib.check(rc)
-        return self
-
-    def _add_dense_repacked(self, X, max_count, max_total):
-        """Layouts the vector loads cannot take (odd row pitch / K with many columns): copy into
-        a 16-byte-aligned matrix whose K is padded with zero columns, run that, keep columns < K.
-        Costs one extra pass; only awkward layouts come here."""
-        # both element types run in chunks of 8 columns (int32: the packed kernel), 8 chunks per lane
-        Kp = -(-self.K // 8) * 8
-        if Kp // 8 > 64 * 8:
-            return self._add_dense_as_csr(X, max_count, max_total)
-        Xp = torch.zeros((X.shape[0], Kp), dtype=X.dtype, device=self.device)
-        Xp[:, :self.K] = X
-        tmp = DeviceStats(Kp, max_count, max_total, device=self.device)
-        with _on(self.device):
-            ws, wsb = tmp._workspace(X.shape[0])
-            fn = (_lib.lib().dme_stats_dense_i32 if X.dtype == torch.int32
-                  else _lib.lib().dme_stats_dense_u16)
-            _lib.check(fn(Xp.data_ptr(), Xp.shape[0], Kp, Kp, _ptr(tmp.hist), tmp.nbins,
-                          _ptr(tmp.histV), tmp.tbins, _ptr(tmp.init_acc), _ptr(tmp.status),
-                          ws, wsb, _stream()))
-        cut = DeviceStats(self.K, tmp.nbins - 1, tmp.tbins - 1, device=self.device)
-        cut.hist = tmp.hist.view(Kp, tmp.nbins)[:self.K].contiguous().view(-1)
-        cut.histV, cut.status = tmp.histV, tmp.status
-        cut.init_acc = tmp.init_acc[:self.K].contiguous()
-        return self.merge_(cut)
-
-    def _add_dense_as_csr(self, X, max_count, max_total):
-        """Dense rows wider than the dense kernels take (K > 4096): compress to
-        CSR on the device (torch, row blocks) and use the CSR entry."""
-        step = max(1, (32 << 20) // max(self.K, 1))
-        for lo in range(0, X.shape[0], step):
-            blk = X[lo:lo + step]
-            if blk.dtype == torch.uint16:
-                blk = blk.view(torch.int16).to(torch.int32) & 0xFFFF
-            nz = torch.nonzero(blk)
-            counts = torch.bincount(nz[:, 0], minlength=blk.shape[0])
-            rowptr = torch.zeros(blk.shape[0] + 1, dtype=torch.int64, device=self.device)
-            rowptr[1:] = torch.cumsum(counts, 0)
-            self.add_csr(rowptr, nz[:, 1].to(torch.int32).contiguous(),
-                         blk[nz[:, 0], nz[:, 1]].to(torch.int32).contiguous(),
-                         max_count=max_count, max_total=max_total)
+            ws, wsb = self._workspace(X.shape[0], X)
+            # rows wider than the dense kernels take (uint16: 32 768 columns, int32: 16 384) are
+            # refused with DME_ERR_UNSUPPORTED: such data belongs in add_csr
+            _lib.check(fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
+                          self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
+                          _ptr(self.status), ws, wsb, _stream()))
         return self
 
     def add_csr(self, rowptr, colidx, vals, max_count=None, max_total=None):

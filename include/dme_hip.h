@@ -79,15 +79,22 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  * The caller must check status[1..3] == 0 and status[6] == 0 (they are data errors, reported after the fact so
  * that the pass stays asynchronous).
  *
- * X is row-major, `ld` elements between rows (ld >= K).  Dense kernels need
- * ceil(K / E / 64) <= 8 where E is the largest power of two <= 16/sizeof(elem) that divides K, ld
- * and the element offset of X (K <= 4096 for 16-byte-aligned uint16 rows); int32 rows with
- * K % 8 == 0, K >= 512 and 16-byte-aligned rows run in chunks of 8 columns like uint16 rows (K <= 4096;
- * counts of 65536 and more are legal and settled one by one).  Otherwise DME_ERR_UNSUPPORTED (use
- * the CSR entry).
- * workspace: dme_stats_workspace_bytes(N, K) bytes [dev], 256-byte aligned.
+ * X is row-major, `ld` elements between rows (ld >= K).  Rows whose start and pitch are 16-byte
+ * aligned and whose K is a multiple of 8 are read as they lie, in 16-byte vectors: uint16 up to
+ * K = 32 768, int32 up to K = 16 384 (from 512 columns on int32 rows run in chunks of 8 columns like
+ * uint16 rows; counts of 65536 and more are legal and settled one by one).  Rows of more than 4096
+ * uint16 / 2048 int32 columns are split over teams of 2, 4 or 8 waves.  Other layouts (odd pitch,
+ * K not a multiple of the vector) are read in narrower vectors of E elements while
+ * ceil(K / E / 64) <= 8, and otherwise STAGED: copied, a block of rows at a time, into a padded
+ * 16-byte-aligned area behind the workspace (one extra read and write of X).  Beyond the column
+ * limits: DME_ERR_UNSUPPORTED (use the CSR entry).
+ * workspace [dev], 256-byte aligned: dme_stats_workspace_bytes(N, K) bytes, plus
+ * dme_stats_staging_bytes(X, N, K, ld, sizeof(elem)) bytes (0 unless this layout is staged; any
+ * amount that holds 4096 rows of K rounded up to 8 columns will do, more means fewer rounds).
  * ------------------------------------------------------------------------------------------- */
 int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);
+int64_t dme_stats_staging_bytes(const void* X /*[dev], only its alignment is looked at*/, int64_t N,
+                                int64_t K, int64_t ld, int elem_bytes);
 
 int dme_stats_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
                         uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,

@@ -238,21 +238,84 @@ def test_large_synthetic_properties(oracle):
         assert out["n_iters"] == ref["n_iters"] and out["n_evals"] == ref["n_evals"]
 
 
-def test_wide_dense_matrix_goes_through_csr(oracle):
-    """K beyond the dense kernels' range (8 vectors per lane) still works: the host layer
-    compresses the rows to CSR on the device."""
+WIDE = [
+    # (N, K, ld, dtype): rows split over teams of 2 / 4 / 8 waves, every J the teams are built for,
+    # the team edges, staged layouts (odd pitch or K, then the same kernels on the padded copy)
+    (700, 4104, 4104, "u16"), (300, 5120, 5120, "u16"), (300, 6000, 6000, "u16"),
+    (300, 7168, 7176, "u16"), (260, 8192, 8192, "u16"), (150, 8200, 8200, "u16"),
+    (150, 12000, 12000, "u16"), (120, 16384, 16384, "u16"), (90, 16392, 16392, "u16"),
+    (80, 24000, 24000, "u16"), (70, 32768, 32768, "u16"),
+    (500, 2056, 2056, "i32"), (500, 3000, 3000, "i32"), (400, 4096, 4096, "i32"),
+    (300, 4104, 4104, "i32"), (200, 6000, 6008, "i32"), (150, 8192, 8192, "i32"),
+    (100, 12000, 12000, "i32"), (90, 16384, 16384, "i32"),
+    (300, 1001, 1001, "u16"), (300, 4097, 4099, "u16"), (200, 6001, 6001, "u16"),
+    (9000, 999, 999, "u16"), (300, 1001, 1001, "i32"), (200, 3001, 3003, "i32"),
+    (150, 5000, 5002, "i32"),
+]
+
+
+@pytest.mark.parametrize("N,K,ld,dtype", WIDE)
+def test_wide_and_staged_rows_bit_exact_vs_oracle(oracle, N, K, ld, dtype):
+    """Rows wider than one wave takes (teams of waves share a row) and layouts that the library
+    stages first: same statistics as the oracle, through the dense C entry alone."""
     dev = _dev()
-    rng = np.random.default_rng(9)
-    N, K = 300, 6000
-    X = rng.integers(1, 30, size=(N, K)) * (rng.random((N, K)) < 0.01)
-    ref = oracle.append_rows(X.astype(np.int32))
-    for dtype in ("u16", "i32"):
+    rng = np.random.default_rng(K * 7 + N)
+    npdt = np.uint16 if dtype == "u16" else np.int32
+    X = rng.integers(1, 30, size=(N, ld)) * (rng.random((N, ld)) < 0.03)
+    # counts beyond the LDS bins (few of those with rows this wide), in the first and last columns
+    X[rng.integers(0, N, 20), rng.integers(0, K, 20)] = rng.integers(100, 60000, 20)
+    X[0, 0], X[N - 1, K - 1], X[N // 2, K - 1] = 77, 78, 1
+    if dtype == "i32":
+        X[1, K // 2] = 70000
+    Xd = torch.from_numpy(X.astype(npdt)).cuda()[:, :K]
+    ref = oracle.append_rows(X[:, :K].astype(npdt))
+    st = dev.DeviceStats(K)
+    st.add_dense(Xd)
+    info = st.check()
+    assert info["rows"] == N
+    assert info["max_count"] == int(X[:, :K].max())
+    assert info["max_total"] == int(X[:, :K].sum(axis=1).max())
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
+
+
+def test_staged_rows_in_several_rounds(oracle):
+    """A staging area that holds a part of the rows only: the rounds add up."""
+    from bayespy_amd import _lib
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    N, K = 9000, 1001
+    X = (rng.integers(1, 9, size=(N, K)) * (rng.random((N, K)) < 0.05)).astype(np.uint16)
+    Xd = torch.from_numpy(X).cuda()
+    st = dev.DeviceStats(K, 8, int(X.sum(axis=1).max()))
+    L = _lib.lib()
+    assert L.dme_stats_staging_bytes(Xd.data_ptr(), N, K, K, 2) == N * 1008 * 2
+    need = L.dme_stats_workspace_bytes(N, K) + 4096 * 1008 * 2 + 256  # 4096 of the 9000 rows
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    off = (-ws.data_ptr()) % 256
+    _lib.check(L.dme_stats_dense_u16(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins,
+                                     st.histV.data_ptr(), st.tbins, st.init_acc.data_ptr(),
+                                     st.status.data_ptr(), ws.data_ptr() + off, need,
+                                     torch.cuda.current_stream().cuda_stream))
+    assert st.check()["rows"] == N
+    ref = oracle.append_rows(X)
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
+    # without the staging bytes the call is refused, and says what it needs
+    with pytest.raises(Exception, match="staged"):
+        _lib.check(L.dme_stats_dense_u16(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins,
+                                         st.histV.data_ptr(), st.tbins, st.init_acc.data_ptr(),
+                                         st.status.data_ptr(), ws.data_ptr() + off,
+                                         L.dme_stats_workspace_bytes(N, K),
+                                         torch.cuda.current_stream().cuda_stream))
+
+
+def test_rows_beyond_the_dense_range_are_refused():
+    dev = _dev()
+    for K, dt in ((32776, torch.uint16), (16392, torch.int32)):
         st = dev.DeviceStats(K)
-        st.add_dense(_to_dev(X, dtype))
-        info = st.check()
-        assert info["rows"] == N
-        _assert_uv_equal(st.finalize(), ref)
-        np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+        with pytest.raises(NotImplementedError, match="CSR"):
+            st.add_dense(torch.zeros((4, K), dtype=dt, device="cuda"), max_count=1, max_total=1)
 
 
 def _csr_direct(dev, rowptr, colidx, vals, K, nbins, tbins, partitioned):
