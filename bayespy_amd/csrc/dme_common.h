@@ -56,6 +56,18 @@ __device__ __forceinline__ u32 dme_wave_sum_u32(u32 v) {
            (u32)__builtin_amdgcn_readlane((int)v, 32) + (u32)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// Inclusive prefix sum over the 64 lanes: four row_shr steps inside the rows of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the rows' sums over (lanes without a source add 0).  VALU only.
+__device__ __forceinline__ u32 dme_wave_incl_scan_u32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
 __device__ __forceinline__ u32 dme_wave_max_u32(u32 v) {
     v = max(v, dme_dpp_u32<DME_DPP_QUAD_XOR1>(v));
     v = max(v, dme_dpp_u32<DME_DPP_QUAD_XOR2>(v));

@@ -55,6 +55,8 @@ struct StatsArgs {
     int CW;     // side-by-side rows: LDS words per (j, p) group of a bin row (C, or 64 = one per lane)
     int steps;  // > 0: interleaved row mapping, loop steps per workgroup; 0: one contiguous slab each
     int adjacent;  // a wave's RB rows of a loop step are adjacent rows (see the kernel)
+    int RC;        // side-by-side rows: copies of a column's words in a bin row (1 ... R; row slot r
+                   // adds to copy r % RC)
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -163,7 +165,8 @@ struct StatsCfg {
 // int32 kernel, whose fp64 accumulators and raw buffers fill the register file) are split over TW
 // waves: wave t of a team takes the vectors 64 * (t + TW * j) + lane, the waves' partial row totals
 // meet in LDS (a counter per team, two sets of slots), everything else is per wave as before.  The LDS image keeps its layout (vector index t + TW * j where a one-wave row has j).
-template <typename T, int E, int J, bool MULTI, bool PACK, int TW>
+// SCAN (side-by-side rows of more than 8 lanes): row totals from a DPP prefix sum over the wave.
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
@@ -258,7 +261,11 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     // same-address LDS atomics serialise (K = 16: 1.25 -> 0.89 ms for 4 GB; hist_reduce_kernel adds
     // the row slots' words of a column together).  With few rows per wave the narrower layout
     // measured 1 % faster.
-    const u32 laneWordByte = (u32)((MULTI && CW == 64) ? lane : c) * 4u + (u32)(tw * PW * CW) * 4u;
+    // As many copies as the count bins leave room for (a.RC): counts beyond the LDS bins go to global
+    // atomics, which for a handful of columns all land on a few addresses (K = 8 with counts up to
+    // 500: 72 ms for 8 GB with a word per lane and 150 bins, against 2.3 ms).
+    const u32 laneWordByte =
+        (u32)(MULTI ? (r % a.RC) * C + c : c) * 4u + (u32)(tw * PW * CW) * 4u;
     char* ldsHb = (char*)ldsH;
     const T* Xp = (const T*)a.X;
     const long long nbins = a.nbins, tbins = a.tbins;
@@ -286,6 +293,29 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
         }
     };
 
+    // side-by-side rows: the total of this lane's row from the lanes' sums.  Rows of more than 8
+    // lanes (SCAN): a prefix sum over the wave in DPP steps, then the difference of its values at
+    // the row's last lane and at the lane before its first (two ds_bpermute; K = 200: 2.20 -> 2.01
+    // ms for 8 GB).  Shorter rows: a shuffle scan inside the row (log2(C) + 1 ds_bpermute, which
+    // measured faster up to C = 8; a kernel that holds both measured slower than either).
+    const int lastLane = min(r * C + C - 1, 63), prevLane = max(r * C - 1, 0);
+    auto multi_total = [&](u32 s) -> u32 {
+        if constexpr (SCAN) {
+            const u32 incl = dme_wave_incl_scan_u32(s);
+            const u32 hi = (u32)__shfl((int)incl, lastLane);
+            const u32 lo = (u32)__shfl((int)incl, prevLane);
+            return r > 0 ? hi - lo : hi;
+        } else {
+            u32 incl = s;
+#pragma unroll
+            for (int dd = 1; dd < 8 && dd < C; dd <<= 1) {  // lanes of one row: c < C
+                u32 up = __shfl_up(incl, dd);
+                if (c >= dd) incl += up;
+            }
+            return (u32)__shfl((int)incl, lastLane);
+        }
+    };
+
     auto process_buf = [&](Buf& b, long long tile, int parity) {
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
@@ -298,14 +328,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
 #pragma unroll
                     for (int q = 0; q < ND; ++q) s = __builtin_amdgcn_sad_u16(b.d[rb][j][q], 0u, s);
                 if constexpr (MULTI) {
-                    u32 incl = s;
-#pragma unroll
-                    for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
-                        u32 up = __shfl_up(incl, dd);
-                        if (c >= dd) incl += up;
-                    }
-                    int last = r * C + C - 1;
-                    tot[rb] = __shfl(incl, last > 63 ? 63 : last);
+                    tot[rb] = multi_total(s);
                 } else {
                     tot[rb] = dme_wave_sum_u32(s);
                 }
@@ -324,14 +347,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                     }
                 if (__builtin_expect(!__any(m >= (1u << 20)), 1)) {
                     if constexpr (MULTI) {
-                        u32 incl = s32;
-#pragma unroll
-                        for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
-                            u32 up = __shfl_up(incl, dd);
-                            if (c >= dd) incl += up;
-                        }
-                        int last = r * C + C - 1;
-                        tot[rb] = (SumT)__shfl(incl, last > 63 ? 63 : last);
+                        tot[rb] = (SumT)multi_total(s32);
                     } else {
                         tot[rb] = (SumT)dme_wave_sum_u32(s32);
                     }
@@ -680,7 +696,7 @@ struct ReduceArgs {
     u64* histV;
     u64* status;
     long long K;
-    int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi;
+    int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi, RC;
     // the mean accumulators ride in the same launch: blocks from hist_blocks on sum part[g][k]
     long long hist_blocks;
     const double* part;
@@ -754,12 +770,12 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
             const u32 jp = wi / (u32)a.CW, cc = wi - jp * (u32)a.CW;
             const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
             // side-by-side rows: word cc belongs to lane cc = row slot cc / C, column chunk cc % C
-            const bool lanes = a.multi && a.CW == 64 && a.C < 64;
-            const bool live = lanes ? cc < (u32)(a.R * a.C) : true;
+            const bool lanes = a.multi && a.RC > 1;  // RC copies of a column's words
+            const bool live = lanes ? cc < (u32)(a.RC * a.C) : true;
             const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
             if (live && chunk < (u32)a.C) {
                 const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
-                if (lanes && a.R > 1) {  // R words per bin
+                if (lanes) {  // RC words per bin
                     if (slo) atomicAdd(&a.hist[k0 * a.nbins + v], slo);
                     if (shi) atomicAdd(&a.hist[(k0 + 1) * a.nbins + v], shi);
                 } else {
@@ -784,7 +800,7 @@ constexpr int kMaxJPack = 2;  // the same for the packed int32 kernel inside a t
 constexpr long long kRowsPerWgMax = 60000;
 
 struct Plan {
-    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw;
+    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -843,9 +859,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // many side-by-side rows: a word per lane (see the kernel) - when there are rows enough to repay
     // the larger images that every workgroup dumps and hist_reduce_kernel sums (~20 us)
     const bool many_rows = N >= 4000000;
-    const int CW = (p.multi && (p.R < 16 || !many_rows)) ? (int)C : 64;
-    p.CW = CW;
-    p.BRW = p.J * p.TW * PW * CW;
+    int RC = (p.multi && p.R >= 16 && many_rows) ? p.R : 1;
     p.block = stats_block(p.J, E, elem_bytes, p.TW);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
@@ -858,6 +872,12 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const long long Vw = (VC * Vstride + 3) & ~3LL;
     const long long hoff = Vw + 2 * WT;
     long long avail = kLdsBudgetBytes / 4 - hoff - 4;
+    // ... as many copies as leave room for all the count bins (halved until they fit)
+    auto words = [&](int rc) { return !p.multi ? 64 : (rc == 1 ? (int)C : (rc == p.R ? 64 : rc * (int)C)); };
+    while (RC > 1 && avail / ((long long)p.J * p.TW * PW * words(RC)) - 1 < nbins - 1) RC /= 2;
+    p.RC = RC;
+    p.CW = words(RC);
+    p.BRW = p.J * p.TW * PW * p.CW;
     long long B = avail / p.BRW - 1;
     if (B > nbins - 1) B = nbins - 1;
     if (B > 65535) B = 65535;
@@ -910,9 +930,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     return DME_OK;
 }
 
-template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1>
+template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1, bool SCAN = false>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW>;
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
     static bool attr_set[64] = {};
     int dev = 0;
@@ -929,7 +949,9 @@ int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
 
 template <typename T, int E>
 int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    if (p.multi) return launch_dense<T, E, 1, true>(a, p, s);
+    if (p.multi)
+        return p.C > 8 ? launch_dense<T, E, 1, true, false, 1, true>(a, p, s)
+                       : launch_dense<T, E, 1, true>(a, p, s);
     switch (p.J) {
         case 1: return launch_dense<T, E, 1, false>(a, p, s);
         case 2: return launch_dense<T, E, 2, false>(a, p, s);
@@ -976,7 +998,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if (p.TW > 1) {
@@ -1021,7 +1043,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     // (a team's image reads like a one-wave row's of TW * J vectors per lane)
     ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
-                  p.multi ? 1 : 0};
+                  p.multi ? 1 : 0, p.RC};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
     ra.hist_blocks = (used + 255) / 256;
     ra.part = (const double*)workspace;

@@ -579,18 +579,23 @@ def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
     assert int(uv.Vi[0]) == N
 
 
-@pytest.mark.parametrize("K,dtype", [(16, "u16"), (2, "i32"), (24, "u16")])
-def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype):
-    """From 4 M rows on, rows that lie 16 or more side by side in a wave use a bin word per lane and
-    a copy of the row-total bins per row slot (summed by hist_reduce_kernel): U/V bit-exact and the
-    mean accumulator to 1e-12 against the oracle's loops at that size; one row total dominates
-    (the fixed-number-of-trials case the layout is for) and a few counts exceed the LDS bins."""
+@pytest.mark.parametrize("K,dtype,big", [(16, "u16", 0), (2, "i32", 0), (24, "u16", 0), (16, "u16", 700),
+                                         (8, "u16", 500), (2, "i32", 100_000)])
+def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype, big):
+    """From 4 M rows on, rows that lie 16 or more side by side in a wave keep several copies of a
+    column's bin words (one per lane when the count bins leave room, fewer when they would not fit)
+    and a copy of the row-total bins per row slot (summed by hist_reduce_kernel): U/V bit-exact and
+    the mean accumulator to 1e-12 against the oracle's loops at that size; one row total dominates
+    (the fixed-number-of-trials case the layout is for); `big`: some counts far beyond the rest
+    (the copies are halved until every bin is in LDS, or, at 100 000, the largest go to global
+    atomics)."""
     N = 4_200_000
     rng = np.random.default_rng(K)
     X = rng.integers(0, 9, size=(N, K), dtype=np.int32)
     X[::3] = 0
     X[::3, 0] = 60                                        # a third of the rows: total exactly 60
-    X[rng.integers(0, N, 50), rng.integers(0, K, 50)] = 700   # beyond the LDS bins
+    if big:
+        X[rng.integers(0, N, 5000), rng.integers(0, K, 5000)] = rng.integers(61, big + 1, 5000)
     ref = oracle.append_rows(X.astype(np.uint16) if dtype == "u16" else X)
     st, uv, info = _build(X, dtype)
     assert info["rows"] == N
