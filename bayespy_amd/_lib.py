@@ -46,6 +46,10 @@ SIGNATURES = {
     "dme_shard_message_words": (_i64, [_i64, _i64, _i64, _i64]),
     "dme_shard_pack": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_shard_unpack": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "dme_shard_extents": (_int, [_vp, _i64, _i64, _vp, _vp]),
+    "dme_shard_offsets": (_int, [_vp, _i64, _vp, _vp]),
+    "dme_shard_compact": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "dme_shard_expand": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "dme_shard_message_words32": (_i64, [_i64, _i64, _i64, _i64]),
     "dme_shard_pack32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_shard_unpack32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

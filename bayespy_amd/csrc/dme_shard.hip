@@ -138,7 +138,120 @@ __global__ __launch_bounds__(SHARD_BLOCK) void shard_unpack32_kernel(
     }
 }
 
+// ---- compact form of the count histograms for large K --------------------------------------------
+// hist is K x nbins with nbins set by the largest count of ANY column; with many columns (bag of
+// words: K = 50 000) nearly all of them stop far below it.  The bins 1 .. ext[k] of every column,
+// laid end to end, are what needs to travel: ext[k] = the column's largest occupied bin, agreed
+// over the ranks by a MAX all-reduce; the offsets are its prefix sums.  dme_shard_pack(32) then takes
+// the compact array in place of hist.
+constexpr int COLS_PER_BLOCK = SHARD_BLOCK / 64;  // a wave per column
+
+__global__ __launch_bounds__(SHARD_BLOCK) void shard_extents_kernel(const u64* hist, long long K,
+                                                                    long long nbins, long long* ext) {
+    const int lane = threadIdx.x & 63;
+    for (long long k = (long long)blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6); k < K;
+         k += (long long)gridDim.x * COLS_PER_BLOCK) {
+        const u64* row = hist + k * nbins;
+        u64 m = 0;
+        for (long long v = 1 + lane; v < nbins; v += 64)
+            if (row[v]) m = (u64)v;  // v grows: the last hit is the lane's largest
+        m = dme_wave_max_u64(m);
+        if (lane == 0) ext[k] = (long long)m;
+    }
+}
+
+// off[k] = ext[0] + ... + ext[k-1], off[K] = the compact length.  One workgroup: a contiguous run of
+// columns per thread, the threads' sums scanned in LDS.
+__global__ __launch_bounds__(1024) void shard_offsets_kernel(const long long* ext, long long K,
+                                                             long long* off) {
+    __shared__ long long sh[1024];
+    const long long per = (K + 1023) / 1024;
+    const long long lo = (long long)threadIdx.x * per, hi = lo + per < K ? lo + per : K;
+    long long s = 0;
+    for (long long k = lo; k < hi; ++k) s += ext[k] > 0 ? ext[k] : 0;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    long long run = sh[threadIdx.x] - s;  // exclusive
+    for (long long k = lo; k < hi; ++k) {
+        off[k] = run;
+        run += ext[k] > 0 ? ext[k] : 0;
+    }
+    if (threadIdx.x == 1023) off[K] = sh[1023];
+}
+
+// TO_COMPACT: compact[off[k] + v - 1] = hist[k][v] for v in 1 .. off[k+1] - off[k];
+// otherwise the way back: hist[k][v] = that word, and 0 in every other bin of the row.
+template <bool TO_COMPACT>
+__global__ __launch_bounds__(SHARD_BLOCK) void shard_compact_kernel(u64* hist, long long K,
+                                                                    long long nbins,
+                                                                    const long long* off,
+                                                                    u64* compact) {
+    const int lane = threadIdx.x & 63;
+    for (long long k = (long long)blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6); k < K;
+         k += (long long)gridDim.x * COLS_PER_BLOCK) {
+        const long long o = off[k];
+        const long long n = off[k + 1] - o;  // agreed over the ranks: may exceed this rank's bins
+        u64* row = hist + k * nbins;
+        if constexpr (TO_COMPACT) {
+            for (long long v = 1 + lane; v <= n; v += 64) compact[o + v - 1] = v < nbins ? row[v] : 0ULL;
+        } else {
+            for (long long v = lane; v < nbins; v += 64)
+                row[v] = (v >= 1 && v <= n) ? compact[o + v - 1] : 0ULL;
+        }
+    }
+}
+
+long long shard_col_grid(long long K) {
+    long long grid = (K + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
+    if (grid > 8192) grid = 8192;
+    return grid < 1 ? 1 : grid;
+}
+
 }  // namespace
+
+extern "C" int dme_shard_extents(const uint64_t* hist, int64_t K, int64_t nbins, int64_t* ext,
+                                 void* stream) {
+    DME_REQUIRE(hist && ext && K >= 1 && nbins >= 1, "bad arguments");
+    hipLaunchKernelGGL(shard_extents_kernel, dim3((unsigned)shard_col_grid(K)), dim3(SHARD_BLOCK), 0,
+                       (hipStream_t)stream, (const u64*)hist, (long long)K, (long long)nbins,
+                       (long long*)ext);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_shard_offsets(const int64_t* ext, int64_t K, int64_t* off, void* stream) {
+    DME_REQUIRE(ext && off && K >= 1, "bad arguments");
+    hipLaunchKernelGGL(shard_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       (const long long*)ext, (long long)K, (long long*)off);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_shard_compact(const uint64_t* hist, int64_t K, int64_t nbins, const int64_t* off,
+                                 uint64_t* compact, void* stream) {
+    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1, "bad arguments");
+    hipLaunchKernelGGL(shard_compact_kernel<true>, dim3((unsigned)shard_col_grid(K)),
+                       dim3(SHARD_BLOCK), 0, (hipStream_t)stream, (u64*)hist, (long long)K,
+                       (long long)nbins, (const long long*)off, (u64*)compact);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_shard_expand(const uint64_t* compact, int64_t K, int64_t nbins,
+                                const int64_t* off, uint64_t* hist, void* stream) {
+    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1, "bad arguments");
+    hipLaunchKernelGGL(shard_compact_kernel<false>, dim3((unsigned)shard_col_grid(K)),
+                       dim3(SHARD_BLOCK), 0, (hipStream_t)stream, (u64*)hist, (long long)K,
+                       (long long)nbins, (const long long*)off, (u64*)compact);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
 
 extern "C" int64_t dme_shard_message_words32(int64_t nh, int64_t nv, int64_t K, int64_t world) {
     if (nh < 0 || nv < 0 || K < 1 || world < 1) return -1;

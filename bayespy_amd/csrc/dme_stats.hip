@@ -922,8 +922,6 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         if (pack) p.steps = 0;
         // rows that share cache lines with their neighbours (pitch not a multiple of 128 bytes)
         p.adjacent = (!p.multi && (ld * elem_bytes) % 128 != 0) ? 1 : 0;
-        if (const char* e = getenv("DME_STATS_ADJ")) p.adjacent = atoi(e);  // timing experiments
-        if (getenv("DME_STATS_CONTIGUOUS")) p.steps = 0;  // timing experiments: one slab per workgroup
         if (p.steps == 0) p.grid = (N + rpw - 1) / rpw;
     }
     *pl = p;

@@ -420,19 +420,20 @@ class DeviceStats:
         return int(self.status[0].cpu())
 
     # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
-    def allreduce(self, group=None, same_extents=False, rows_bound=None):
+    def allreduce(self, group=None, same_extents=False, rows_bound=None, compact=None, info=None):
         """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs): one integer SUM
         all-reduce, see parallel.allreduce_stats_tensors.  `same_extents=True` when every rank
         passed the same max_count / max_total (no extent agreement round, no host sync);
         `rows_bound` (the same on every rank): an upper bound on the rows of the whole job - below
-        2^32 the message travels in 32-bit words, half the bytes.  After
-        it every rank holds the global statistics and solves redundantly; there is no
-        per-iteration communication."""
+        2^32 the message travels in 32-bit words, half the bytes; `compact` (default: from 4096
+        columns on): only the occupied bins of every column travel; `info`: a dict that receives
+        the message size.  After it every rank holds the global statistics and solves redundantly;
+        there is no per-iteration communication."""
         from .parallel import allreduce_stats_tensors
         (self.hist, self.histV, self.status, self.init_acc, self.nbins,
          self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
                                                self.K, self.nbins, self.tbins, group, same_extents,
-                                               rows_bound)
+                                               rows_bound, compact, info)
         return self
 
     def merge_(self, other):

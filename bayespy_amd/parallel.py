@@ -36,8 +36,11 @@ def grow_vec(v, new_len):
     return new
 
 
+COMPACT_MIN_K = 4096  # from this many columns on the count histograms travel in compact form
+
+
 def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
-                            same_extents=False, rows_bound=None):
+                            same_extents=False, rows_bound=None, compact=None, info=None):
     """All-reduces one rank's partial statistics.  Tensors may live on any device the process
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
@@ -56,22 +59,129 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     `rows_bound`: an upper bound on the rows of the whole job that EVERY rank passes alike.  Below
     2^32 no bin can need more than 32 bits, and the message travels in 32-bit words (bins one word
     each, the rest as (lo, hi) pairs; dme_shard_pack32 / dme_shard_unpack32): half the bytes on the
-    wire (SURVEY 8e "uint32 if N < 2^32")."""
+    wire (SURVEY 8e "uint32 if N < 2^32").
+
+    `compact` (default: K >= COMPACT_MIN_K; the same on every rank): the count histograms travel as
+    the bins 1 .. ext[k] of every column laid end to end, ext[k] the column's largest occupied bin
+    over all ranks (one MAX all-reduce of K + 2 words, which also agrees the extents, and one host
+    read of the compact length).  With many columns nearly all of them stop far below the largest
+    count of any: BASELINE configs[3] (K = 50 000) sends a few MB instead of K x nbins words.
+
+    `info` (a dict, optional) receives message_bytes and, in compact form, extents_bytes."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return hist, histV, status, init_acc, nbins, tbins
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if compact is None:
+        compact = K >= COMPACT_MIN_K
     nb, tb = nbins, tbins
-    if not same_extents:
+    off = None
+    if compact:
+        # the columns' extents, and with them the two histogram extents, agreed in one MAX
+        ext = torch.empty(K + 2, dtype=torch.int64, device=hist.device)
+        ext[K], ext[K + 1] = nbins, tbins
+        _column_extents(hist, K, nbins, ext)
+        _sync_for_gloo(ext, group)
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
+        off = torch.empty(K + 1, dtype=torch.int64, device=hist.device)
+        _column_offsets(ext, K, off)
+        nb, tb, total = (int(v) for v in torch.stack([ext[K], ext[K + 1], off[K]]).cpu())
+        histV = grow_vec(histV, tb)
+        full, full_bins = hist, nbins
+        hist = _to_compact(full, K, full_bins, off, total)
+        if info is not None:
+            info["extents_bytes"] = (K + 2) * 8
+    elif not same_extents:
         ext = torch.tensor([nbins, tbins], dtype=torch.int64, device=hist.device)
         dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
         nb, tb = (int(v) for v in ext.cpu())
         hist = grow_hist(hist, K, nbins, nb)
         histV = grow_vec(histV, tb)
+    out = _sum_message(hist, histV, status, init_acc, K, group, world, rank, rows_bound, info)
+    if compact:
+        out = (_from_compact(out[0], K, nb, off),) + out[1:]
+    return out + (nb, tb)
+
+
+def _sync_for_gloo(t, group):
+    """Rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor was seen
+    to hang when issued behind a long-running kernel of the same process; RCCL ("nccl") orders
+    itself on the stream and needs no host sync."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(t.device).synchronize()
+
+
+def _column_extents(hist, K, nbins, ext):
+    """ext[k] = the largest occupied bin of column k (dme_shard_extents; torch for host tensors)."""
+    if hist.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        with _on(hist.device):
+            _lib.check(_lib.lib().dme_shard_extents(_ptr(hist), K, nbins, _ptr(ext), _stream()))
+    else:
+        bins = torch.arange(nbins, dtype=torch.int64)
+        ext[:K] = ((hist.view(K, nbins) != 0) * bins).max(dim=1).values
+
+
+def _column_offsets(ext, K, off):
+    if ext.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        with _on(ext.device):
+            _lib.check(_lib.lib().dme_shard_offsets(_ptr(ext), K, _ptr(off), _stream()))
+    else:
+        off[0] = 0
+        off[1:] = torch.cumsum(ext[:K], 0)
+
+
+def _to_compact(hist, K, nbins, off, total):
+    out = torch.empty(max(total, 1), dtype=torch.int64, device=hist.device)[:total]
+    if total == 0:
+        return out
+    if hist.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        with _on(hist.device):
+            _lib.check(_lib.lib().dme_shard_compact(_ptr(hist), K, nbins, _ptr(off), _ptr(out),
+                                                    _stream()))
+        return out
+    n = (off[1:] - off[:-1])
+    wide = max(nbins, int(n.max()) + 1)
+    h = grow_hist(hist, K, nbins, wide).view(K, wide)
+    bins = torch.arange(wide, dtype=torch.int64)
+    return h[(bins[None, :] >= 1) & (bins[None, :] <= n[:, None])].contiguous()
+
+
+def _from_compact(comp, K, nbins, off):
+    hist = torch.empty(K * nbins, dtype=torch.int64, device=comp.device)
+    if comp.is_cuda:
+        from . import _lib
+        from .device import _on, _ptr, _stream
+        if comp.numel() == 0:
+            return hist.zero_()
+        with _on(comp.device):
+            _lib.check(_lib.lib().dme_shard_expand(_ptr(comp), K, nbins, _ptr(off), _ptr(hist),
+                                                   _stream()))
+        return hist
+    hist.zero_()
+    n = (off[1:] - off[:-1])
+    bins = torch.arange(nbins, dtype=torch.int64)
+    hist.view(K, nbins)[(bins[None, :] >= 1) & (bins[None, :] <= n[:, None])] = comp
+    return hist
+
+
+def _sum_message(hist, histV, status, init_acc, K, group, world, rank, rows_bound, info):
+    """The SUM all-reduce of one message; `hist` is any flat array of bins (K x nbins, or compact)."""
+    import torch.distributed as dist
     nh, nv = hist.numel(), histV.numel()
     if rows_bound is not None and 0 <= int(rows_bound) < (1 << 32):
-        return _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, rank)
+        if info is not None:
+            info["message_bytes"] = 4 * (nh + nv + 2 * (8 + world * (2 + K)))
+        return _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank)
     nmsg = nh + nv + 8 + world * (2 + K)
+    if info is not None:
+        info["message_bytes"] = 8 * nmsg
     if hist.is_cuda:
         from . import _lib
         from .device import _on, _ptr, _stream
@@ -80,15 +190,11 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
             msg = torch.empty(nmsg, dtype=torch.int64, device=hist.device)
             _lib.check(L.dme_shard_pack(_ptr(hist), nh, _ptr(histV), nv, _ptr(status),
                                         _ptr(init_acc), K, rank, world, _ptr(msg), _stream()))
-            if dist.get_backend(group) == "gloo":
-                # rehearsals with several gloo ranks on one card: gloo's staged copy of a device
-                # tensor was seen to hang when issued behind a long-running kernel of the same
-                # process; RCCL ("nccl") orders itself on the stream and needs no host sync
-                torch.cuda.current_stream(msg.device).synchronize()
+            _sync_for_gloo(msg, group)
             dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
             acc = torch.empty(K, dtype=torch.float64, device=hist.device)
             _lib.check(L.dme_shard_unpack(_ptr(msg), nh, nv, K, world, _ptr(acc), _stream()))
-        return msg[:nh], msg[nh:nh + nv], msg[nh + nv:nh + nv + 8], acc, nb, tb
+        return msg[:nh], msg[nh:nh + nv], msg[nh + nv:nh + nv + 8], acc
     msg = torch.zeros(nmsg, dtype=torch.int64)
     msg[:nh] = hist
     msg[nh:nh + nv] = histV
@@ -104,10 +210,10 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     acc = parts[0].clone()
     for r in range(1, world):  # fixed order: bit-identical on every rank
         acc += parts[r]
-    return msg[:nh], msg[nh:nh + nv], out_status, acc, nb, tb
+    return msg[:nh], msg[nh:nh + nv], out_status, acc
 
 
-def _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, rank):
+def _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank):
     """The 32-bit form of the message (include/dme_hip.h, dme_shard_pack32): int32 SUM all-reduce."""
     import torch.distributed as dist
     nh, nv = hist.numel(), histV.numel()
@@ -120,15 +226,14 @@ def _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, r
             msg = torch.empty(nmsg, dtype=torch.int32, device=hist.device)
             _lib.check(L.dme_shard_pack32(_ptr(hist), nh, _ptr(histV), nv, _ptr(status),
                                           _ptr(init_acc), K, rank, world, _ptr(msg), _stream()))
-            if dist.get_backend(group) == "gloo":
-                torch.cuda.current_stream(msg.device).synchronize()  # see allreduce_stats_tensors
+            _sync_for_gloo(msg, group)
             dist.all_reduce(msg, op=dist.ReduceOp.SUM, group=group)
             out = torch.empty(nh + nv + 8, dtype=torch.int64, device=hist.device)
             acc = torch.empty(K, dtype=torch.float64, device=hist.device)
             _lib.check(L.dme_shard_unpack32(_ptr(msg), nh, nv, K, world, _ptr(out),
                                             out.data_ptr() + 8 * nh, out.data_ptr() + 8 * (nh + nv),
                                             _ptr(acc), _stream()))
-        return out[:nh], out[nh:nh + nv], out[nh + nv:], acc, nb, tb
+        return out[:nh], out[nh:nh + nv], out[nh + nv:], acc
     # host tensors (gloo tests): the same message with torch
     cap = 0xFFFFFFFF // world
     tail = torch.zeros(8 + world * (2 + K), dtype=torch.int64)
@@ -152,4 +257,4 @@ def _allreduce_words32(hist, histV, status, init_acc, K, nb, tb, group, world, r
     acc = parts[0].clone()
     for r in range(1, world):  # fixed order: bit-identical on every rank
         acc += parts[r]
-    return words[:nh].clone(), words[nh:nh + nv].clone(), out_status, acc, nb, tb
+    return words[:nh].clone(), words[nh:nh + nv].clone(), out_status, acc

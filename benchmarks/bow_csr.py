@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--solve", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true")
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--dense-message", action="store_true",
+                    help="all-reduce K x nbins words instead of the occupied bins of every column")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -165,7 +167,12 @@ def main():
             t1 = time.perf_counter()
             stw = dev.DeviceStats(args.k, max_count, max_total)
             stw.add_csr(rowptr, colidx, vals, max_count=max_count, max_total=max_total)
-            stw.allreduce(same_extents=True)
+            msg_info = {}
+            te0 = time.perf_counter()
+            stw.allreduce(same_extents=True, rows_bound=world * (1 << 28),
+                          compact=not args.dense_message, info=msg_info)
+            torch.cuda.synchronize()
+            t_reduce = time.perf_counter() - te0
             uvw = stw.finalize()
             outw = uvw.solve(stw.cli_init_alphas(), 50, 0.0, trace_alphas=False)
             torch.cuda.synchronize()
@@ -193,6 +200,11 @@ def main():
         line["estimation_ms_all_ranks"] = min(whole) * 1e3
         line["rows_per_s_all_ranks"] = int(rows_all.cpu()[0]) / min(whole)
         line["rows_checked_all_ranks"] = stw.check()["rows"]
+        line["allreduce"] = {"message_bytes": msg_info["message_bytes"],
+                             "extents_bytes": msg_info.get("extents_bytes", 0),
+                             "dense_message_bytes": 4 * (args.k * stw.nbins + stw.tbins),
+                             "form": "dense" if args.dense_message else "compact",
+                             "ms_incl_pack_unpack_last_step": t_reduce * 1e3}
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

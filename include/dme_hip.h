@@ -207,6 +207,27 @@ int dme_shard_unpack32(const uint32_t* msg /*[dev]*/, int64_t nh, int64_t nv, in
                        uint64_t* histV64 /*[dev][nv] out*/, uint64_t* status /*[dev][8] out*/,
                        double* init_acc /*[dev][K] out*/, void* stream);
 
+/* Compact form of hist for many columns (BASELINE configs[3], K = 50 000: nbins is set by the
+ * largest count of any column, nearly every column stops far below it).  What travels are the bins
+ * 1 .. ext[k] of every column laid end to end, `compact`, passed to dme_shard_pack / _pack32 in
+ * place of hist with nh = off[K]:
+ *   dme_shard_extents  ext[k] = the largest occupied bin of column k (0: none)   - then a MAX
+ *                      all-reduce of ext over the ranks (the caller's);
+ *   dme_shard_offsets  off[k] = ext[0] + ... + ext[k-1], off[K] = the compact length;
+ *   dme_shard_compact  compact[off[k] + v - 1] = hist[k*nbins + v],  v in 1 .. ext[k];
+ *   dme_shard_expand   the way back after the sum: fills hist (every bin; zeros outside 1 .. ext[k]).
+ * No counterpart in the reference (one process). */
+int dme_shard_extents(const uint64_t* hist /*[dev][K*nbins]*/, int64_t K, int64_t nbins,
+                      int64_t* ext /*[dev][K] out*/, void* stream);
+int dme_shard_offsets(const int64_t* ext /*[dev][K]*/, int64_t K, int64_t* off /*[dev][K+1] out*/,
+                      void* stream);
+int dme_shard_compact(const uint64_t* hist /*[dev][K*nbins]*/, int64_t K, int64_t nbins,
+                      const int64_t* off /*[dev][K+1]*/, uint64_t* compact /*[dev][off[K]] out*/,
+                      void* stream);
+int dme_shard_expand(const uint64_t* compact /*[dev][off[K]]*/, int64_t K, int64_t nbins,
+                     const int64_t* off /*[dev][K+1]*/, uint64_t* hist /*[dev][K*nbins] out*/,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Solver.  U is dense-padded fp64: U[k][n] = Uf[k*ldU + n] for n < lenU[k]; V = Vf[0..lenV).
  * lenU [K] and lenV [1] are device arrays (as written by dme_suffix_scan).

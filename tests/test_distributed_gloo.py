@@ -32,7 +32,7 @@ def _hist_of(X, K):
     return hist, histV, status, acc, nb, tb
 
 
-def _worker(rank, world, port, X, K, out, same_extents=False, rows_bound=None):
+def _worker(rank, world, port, X, K, out, same_extents=False, rows_bound=None, compact=None):
     sys.path.insert(0, ROOT)
     from bayespy_amd.parallel import allreduce_stats_tensors, shard_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -47,10 +47,11 @@ def _worker(rank, world, port, X, K, out, same_extents=False, rows_bound=None):
         nb, tb = 64, 512
     res = allreduce_stats_tensors(torch.from_numpy(hist.reshape(-1)), torch.from_numpy(histV),
                                   torch.from_numpy(status), torch.from_numpy(acc), K, nb, tb,
-                                  same_extents=same_extents, rows_bound=rows_bound)
+                                  same_extents=same_extents, rows_bound=rows_bound,
+                                  compact=compact, info=(info := {}))
     h, v, st, a, nb2, tb2 = res
     out[rank] = (h.view(K, nb2).numpy().copy(), v.numpy().copy(), st.numpy().copy(),
-                 a.numpy().copy(), nb2, tb2)
+                 a.numpy().copy(), nb2, tb2, info)
     dist.destroy_process_group()
 
 
@@ -73,7 +74,7 @@ def test_allreduce_of_shard_histograms_is_exact(world):
     mp.spawn(_worker, args=(world, _free_port(), X, K, out), nprocs=world, join=True)
     hist, histV, status, acc, nb, tb = _hist_of(X, K)
     for r in range(world):
-        h, v, st, a, nb2, tb2 = out[r]
+        h, v, st, a, nb2, tb2 = out[r][:6]
         assert (nb2, tb2) == (nb, tb)
         assert np.array_equal(h, hist) and np.array_equal(v, histV)
         assert st[0] == N and st[4] == 40 and st[5] == status[5]
@@ -100,7 +101,7 @@ def test_allreduce_with_agreed_extents_is_one_collective():
     mp.spawn(_worker, args=(world, _free_port(), X, K, out, True), nprocs=world, join=True)
     hist, histV, status, acc, nb, tb = _hist_of(X, K)
     for r in range(world):
-        h, v, st, a, nb2, tb2 = out[r]
+        h, v, st, a, nb2, tb2 = out[r][:6]
         assert (nb2, tb2) == (64, 512)
         assert np.array_equal(h[:, :nb], hist) and not h[:, nb:].any()
         assert np.array_equal(v[:tb], histV) and not v[tb:].any()
@@ -121,9 +122,38 @@ def test_allreduce_in_32_bit_words_is_exact(world):
     mp.spawn(_worker, args=(world, _free_port(), X, K, out, True, N), nprocs=world, join=True)
     hist, histV, status, acc, nb, tb = _hist_of(X, K)
     for r in range(world):
-        h, v, st, a, nb2, tb2 = out[r]
+        h, v, st, a, nb2, tb2 = out[r][:6]
         assert np.array_equal(h[:, :nb], hist) and not h[:, nb:].any()
         assert np.array_equal(v[:tb], histV) and not v[tb:].any()
         assert st[0] == N and st[4] == status[4] and st[5] == status[5]
         np.testing.assert_allclose(a, acc, rtol=1e-13)
         assert np.array_equal(a, out[0][3])
+
+
+@pytest.mark.parametrize("world,rows_bound", [(2, None), (3, 1000)])
+def test_allreduce_in_compact_form_is_exact(world, rows_bound):
+    """compact=True: only the bins 1 .. ext[k] of every column travel (ext agreed by a MAX
+    all-reduce together with the two histogram extents); one column holds a count far above the
+    others' and only the last shard sees it, one column is empty; the results are those of the
+    dense message and the message is a fraction of its size."""
+    rng = np.random.default_rng(14)
+    K, N = 40, 600
+    X = rng.integers(0, 4, size=(N, K)) * (rng.random((N, K)) < 0.3)
+    X[:, 7] = 0
+    X[N - 1, 3] = 900
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), X, K, out, False, rows_bound, True), nprocs=world,
+             join=True)
+    hist, histV, status, acc, nb, tb = _hist_of(X, K)
+    dense_words = K * nb + tb
+    for r in range(world):
+        h, v, st, a, nb2, tb2, info = out[r]
+        assert (nb2, tb2) == (nb, tb)
+        assert np.array_equal(h, hist) and np.array_equal(v, histV)
+        assert st[0] == N and st[4] == 900 and st[5] == status[5]
+        np.testing.assert_allclose(a, acc, rtol=1e-13)
+        assert np.array_equal(a, out[0][3])
+        word = 4 if rows_bound else 8
+        assert info["message_bytes"] < word * dense_words / 10
+        assert info["extents_bytes"] == (K + 2) * 8

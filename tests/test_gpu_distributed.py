@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, X, K, out, rows_bound=None):
+def _worker(rank, world, port, X, K, out, rows_bound=None, compact=None):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from bayespy_amd import device
@@ -28,7 +28,9 @@ def _worker(rank, world, port, X, K, out, rows_bound=None):
     lo, hi = shard_rows(X.shape[0], rank, world)
     st = device.DeviceStats(K)
     st.add_dense(torch.from_numpy(np.ascontiguousarray(X[lo:hi])).cuda())
-    if rows_bound is None:
+    if compact:  # extents differ between the ranks; agreed with the columns' extents
+        st.allreduce(compact=True, rows_bound=rows_bound)
+    elif rows_bound is None:
         st.allreduce()
     else:  # the 32-bit message needs agreed extents: size every rank's histograms alike first
         st.reserve(int(X.max()), int(X.sum(axis=1).max()))
@@ -41,8 +43,8 @@ def _worker(rank, world, port, X, K, out, rows_bound=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows_bound", [None, 2000])
-def test_two_ranks_allreduce_then_identical_solve(rows_bound):
+@pytest.mark.parametrize("rows_bound,compact", [(None, None), (2000, None), (None, True), (2000, True)])
+def test_two_ranks_allreduce_then_identical_solve(rows_bound, compact):
     import torch.multiprocessing as mp
     from conftest import load_golden
     fx = load_golden("dirmult_k1000")
@@ -53,7 +55,7 @@ def test_two_ranks_allreduce_then_identical_solve(rows_bound):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, X, fx["K"], out, rows_bound), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, X, fx["K"], out, rows_bound, compact), nprocs=2, join=True)
     ref = [s for s in fx["solves"] if s["variant"] == "DE" and s["init_name"] == "cli"][0]
     for r in range(2):
         U, V, rows, alpha, n_iters = out[r]
@@ -167,3 +169,40 @@ def test_shard_message_kernels_32_bit_words(world, K, nbins, tbins):
     for r in range(1, world):
         ref = ref + accs[r]
     assert np.array_equal(acc_out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("K,nbins,wider", [(1, 2, 0), (7, 5, 0), (300, 700, 0), (5000, 40, 0), (2500, 9, 6)])
+def test_compact_histogram_kernels_match_the_host_code(K, nbins, wider):
+    """dme_shard_extents / _offsets / _compact / _expand against the torch code that host tensors
+    (the gloo tests) take; `wider`: the agreed extents reach beyond this rank's bins (another rank
+    saw larger counts), the compact words there are zeros and the way back fills a wider hist."""
+    from bayespy_amd import parallel
+    g = torch.Generator().manual_seed(K + nbins)
+    hist = torch.randint(0, 3, (K, nbins), generator=g, dtype=torch.int64)
+    hist *= (torch.rand((K, nbins), generator=g) < 0.2)
+    hist[:, 0] = 0
+    hist[K // 2] = 0
+    hist[0, nbins - 1] = 5
+    ext_h = torch.zeros(K + 2, dtype=torch.int64)
+    ext_d = torch.zeros(K + 2, dtype=torch.int64, device="cuda")
+    parallel._column_extents(hist.view(-1), K, nbins, ext_h)
+    parallel._column_extents(hist.view(-1).cuda(), K, nbins, ext_d)
+    assert torch.equal(ext_d.cpu(), ext_h)
+    assert int(ext_h[0]) == nbins - 1 and (K == 1 or int(ext_h[K // 2]) == 0)
+    if wider:
+        ext_h[::3] += wider
+        ext_d[::3] += wider
+    off_h = torch.zeros(K + 1, dtype=torch.int64)
+    off_d = torch.zeros(K + 1, dtype=torch.int64, device="cuda")
+    parallel._column_offsets(ext_h, K, off_h)
+    parallel._column_offsets(ext_d, K, off_d)
+    assert torch.equal(off_d.cpu(), off_h)
+    total = int(off_h[K])
+    c_h = parallel._to_compact(hist.view(-1), K, nbins, off_h, total)
+    c_d = parallel._to_compact(hist.view(-1).cuda(), K, nbins, off_d, total)
+    assert c_h.numel() == total and torch.equal(c_d.cpu(), c_h)
+    nb = nbins + wider
+    back_h = parallel._from_compact(c_h, K, nb, off_h)
+    back_d = parallel._from_compact(c_d, K, nb, off_d)
+    assert torch.equal(back_d.cpu(), back_h)
+    assert torch.equal(back_h.view(K, nb)[:, :nbins], hist) and not back_h.view(K, nb)[:, nbins:].any()
