@@ -280,6 +280,18 @@ class DeviceStats:
         nb = max(self.nbins, int(max_count) + 1)
         tb = max(self.tbins, int(max_total) + 1)
         if nb != self.nbins:
+            # The statistics are kept as K x (max_count + 1) cells: 8 bytes each here and 16 more in
+            # finalize() (integer and fp64 U).  One outlier count sets the width for every column.
+            need = 8 * self.K * nb + 8 * self.K * self.nbins
+            whole = 24 * self.K * nb
+            free = torch.cuda.mem_get_info(self.device)[0]
+            if self.K * nb >= (1 << 40) or need > free:
+                raise MemoryError(
+                    f"statistics for K={self.K} columns with counts up to max_count={nb - 1} take "
+                    f"{whole / 2**30:.1f} GiB on the device (24 bytes x K x (max_count + 1); "
+                    f"{free / 2**30:.1f} GiB are free): the histograms are dense per column, so a "
+                    f"single very large count widens all of them.  Clip or split such rows, or "
+                    f"estimate the heavy columns separately.")
             new = torch.zeros(self.K, nb, dtype=torch.int64, device=self.device)
             new[:, :self.nbins] = self.hist.view(self.K, self.nbins)
             self.hist, self.nbins = new.view(-1), nb

@@ -246,3 +246,31 @@ class _Binary:
 
     def __init__(self, text):
         self.buffer = io.BytesIO(text.encode())
+
+
+def test_documented_deviations_of_the_exception_surface():
+    """gradient / Hessian entries refuse alpha <= 0 like dirichLogProb
+    (the reference returns finite numbers there), a negative cell is an error at check() (the
+    reference skips it), and a count that the dense histograms cannot hold is refused with the bytes
+    named."""
+    import bayespy_amd.dirichletMultinomialEstimation as DME
+    data = DME.CompressedRowData(3)
+    for row in ([1, 2, 0], [0, 1, 1], [2, 0, 3]):
+        data.appendRow(row, 1)
+    bad = [0.5, -0.25, 1.0]
+    for fn in (lambda: DME.priorGradient(bad, data, 0), lambda: DME.priorHessianConst(bad, data),
+               lambda: DME.priorHessianDiag(bad, data),
+               lambda: DME.predictStepUsingHessian([0.1, 0.1, 0.1], bad, data),
+               lambda: DME.predictStepLogSpace([0.1, 0.1, 0.1], bad, data),
+               lambda: DME.dirichLogProb(bad, data, 0)):
+        with pytest.raises(ValueError, match="math domain"):
+            fn()
+    assert DME.testTrialPriors(bad, data, 0) == float("inf")   # DE/dme.py:97-102, as the reference
+    neg = DME.CompressedRowData(3)
+    neg.appendRow([1, -2, 0], 1)
+    with pytest.raises(ValueError, match="negative"):
+        neg.deviceStats().check()
+    from bayespy_amd import device
+    st = device.DeviceStats(1000)
+    with pytest.raises(MemoryError, match="max_count=100000000"):
+        st.reserve(100_000_000, 10)
