@@ -36,7 +36,9 @@ def grow_vec(v, new_len):
     return new
 
 
-COMPACT_MIN_K = 4096  # from this many columns on the count histograms travel in compact form
+COMPACT_MIN_K = 4096  # from this many columns on the count histograms travel in compact form,
+COMPACT_MIN_WORDS = 1 << 20  # or from this many bins on when the ranks agree on nbins beforehand
+                             # (heavy-tailed counts on few columns: BASELINE configs[4], 100 x 1e4)
 
 
 def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
@@ -61,7 +63,8 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     each, the rest as (lo, hi) pairs; dme_shard_pack32 / dme_shard_unpack32): half the bytes on the
     wire (SURVEY 8e "uint32 if N < 2^32").
 
-    `compact` (default: K >= COMPACT_MIN_K; the same on every rank): the count histograms travel as
+    `compact` (default: K >= COMPACT_MIN_K, or same_extents and K * nbins >= COMPACT_MIN_WORDS; the
+    same on every rank): the count histograms travel as
     the bins 1 .. ext[k] of every column laid end to end, ext[k] the column's largest occupied bin
     over all ranks (one MAX all-reduce of K + 2 words, which also agrees the extents, and one host
     read of the compact length).  With many columns nearly all of them stop far below the largest
@@ -73,7 +76,8 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
         return hist, histV, status, init_acc, nbins, tbins
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if compact is None:
-        compact = K >= COMPACT_MIN_K
+        # (a rule every rank evaluates alike: K always is the same, nbins only when agreed beforehand)
+        compact = K >= COMPACT_MIN_K or (same_extents and K * nbins >= COMPACT_MIN_WORDS)
     nb, tb = nbins, tbins
     off = None
     if compact:
