@@ -108,7 +108,11 @@ def main():
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dense-message", action="store_true",
                     help="all-reduce K x nbins words instead of the occupied bins of every column")
+    ap.add_argument("--lib", default=None, help="another build of libdme_hip.so to time (A/B comparisons)")
     args = ap.parse_args()
+    if args.lib:
+        from bayespy_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     import torch
     import torch.distributed as dist
     from bayespy_amd import device as dev
