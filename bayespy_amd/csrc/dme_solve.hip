@@ -402,6 +402,31 @@ struct PartV {
 __device__ __forceinline__ PartV ld_part(const Partial* p) {
     return PartV{{p->s0hi, p->s0lo, p->s1hi, p->s1lo, p->s2}};
 }
+// Adds the slots [0, cnt) of one column in index order (`first`: slot 0 already in registers, the loop
+// then starts at `from` = 1).  Four slots are loaded before the first of them is added: the adds
+// keep their order (same bits as one by one), but a long column - heavy-tailed counts: 38 slots at
+// 9700 bins - no longer pays a memory round trip per slot (BASELINE configs[4]: 0.45 -> 0.36 ms
+// for the 13-iteration solve).
+__device__ __forceinline__ void gather_slots(const Partial* base, long long from, long long cnt,
+                                             const PartV* first, DmeAcc& a0, DmeAcc& a1, double& a2) {
+    auto add = [&](const PartV& p) {
+        a0.add(DmeAcc{p.v[0], p.v[1]});
+        a1.add(DmeAcc{p.v[2], p.v[3]});
+        a2 = __dadd_rn(a2, p.v[4]);
+    };
+    if (first) add(*first);
+    long long i = from;
+    for (; i + 3 < cnt; i += 4) {
+        const PartV p0 = ld_part(base + i), p1 = ld_part(base + i + 1), p2 = ld_part(base + i + 2),
+                    p3 = ld_part(base + i + 3);
+        add(p0);
+        add(p1);
+        add(p2);
+        add(p3);
+    }
+    for (; i < cnt; ++i) add(ld_part(base + i));
+}
+
 template <int NCOL>
 struct GatherPrefetch {
     long long L[NCOL > 0 ? NCOL : 1];
@@ -517,12 +542,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
                 const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
                 DmeAcc a0{0, 0}, a1{0, 0};
                 double a2 = 0.0;
-                for (long long i = 0; i < cnt; ++i) {
-                    const PartV p = i == 0 ? pf->p[c] : ld_part(w.part + k * S + i);
-                    a0.add(DmeAcc{p.v[0], p.v[1]});
-                    a1.add(DmeAcc{p.v[2], p.v[3]});
-                    a2 = __dadd_rn(a2, p.v[4]);
-                }
+                if (cnt > 0) gather_slots(w.part + k * S, 1, cnt, &pf->p[c], a0, a1, a2);
                 column(k, a0, a1, a2);
             }
         }
@@ -533,12 +553,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
             const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
             DmeAcc a0{0, 0}, a1{0, 0};
             double a2 = 0.0;
-            for (long long i = 0; i < cnt; ++i) {
-                const PartV p = ld_part(w.part + k * S + i);
-                a0.add(DmeAcc{p.v[0], p.v[1]});
-                a1.add(DmeAcc{p.v[2], p.v[3]});
-                a2 = __dadd_rn(a2, p.v[4]);
-            }
+            gather_slots(w.part + k * S, 0, cnt, nullptr, a0, a1, a2);
             column(k, a0, a1, a2);
         }
     }
