@@ -432,7 +432,8 @@ class DeviceStats:
         return int(self.status[0].cpu())
 
     # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
-    def allreduce(self, group=None, same_extents=False, rows_bound=None, compact=None, info=None):
+    def allreduce(self, group=None, same_extents=False, rows_bound=None, compact=None, info=None,
+                  force_message=False):
         """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs): one integer SUM
         all-reduce, see parallel.allreduce_stats_tensors.  `same_extents=True` when every rank
         passed the same max_count / max_total (no extent agreement round, no host sync);
@@ -445,7 +446,7 @@ class DeviceStats:
         (self.hist, self.histV, self.status, self.init_acc, self.nbins,
          self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
                                                self.K, self.nbins, self.tbins, group, same_extents,
-                                               rows_bound, compact, info)
+                                               rows_bound, compact, info, force_message)
         return self
 
     def merge_(self, other):

@@ -42,7 +42,8 @@ COMPACT_MIN_WORDS = 1 << 20  # or from this many bins on when the ranks agree on
 
 
 def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
-                            same_extents=False, rows_bound=None, compact=None, info=None):
+                            same_extents=False, rows_bound=None, compact=None, info=None,
+                            force_message=False):
     """All-reduces one rank's partial statistics.  Tensors may live on any device the process
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
@@ -70,9 +71,13 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     read of the compact length).  With many columns nearly all of them stop far below the largest
     count of any: BASELINE configs[3] (K = 50 000) sends a few MB instead of K x nbins words.
 
-    `info` (a dict, optional) receives message_bytes and, in compact form, extents_bytes."""
+    `info` (a dict, optional) receives message_bytes and, in compact form, extents_bytes.
+    `force_message`: build, reduce and read the message even in a group of one rank (rehearsals of
+    the RCCL code path on a single GPU)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return hist, histV, status, init_acc, nbins, tbins
+    if dist.get_world_size(group) == 1 and not force_message:
         return hist, histV, status, init_acc, nbins, tbins
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if compact is None:

@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--sync-steps", action="store_true",
                     help="wait on the host after every timed step instead of enqueueing the steps "
                          "back to back (the headline then equals `sync_ms_per_step`)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: create the process group anyway and send the all-reduce "
+                         "message through it (rehearses the RCCL code path on a single GPU)")
     ap.add_argument("--verify", action="store_true",
                     help="check size-independent properties of the statistics after the run")
     return ap.parse_args()
@@ -86,6 +89,22 @@ def launch_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching %s\n" % (args.gpus, " ".join(cmd)))
     raise SystemExit(subprocess.call(cmd))
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: with NCCL_DEBUG=VERSION (set on the GPU
+    boxes) RCCL prints its banner to stdout from C when the communicator is created, and stdout is
+    for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def main():
@@ -112,13 +131,22 @@ def main():
     local_rank %= ndev  # gloo rehearsals: several ranks share a card
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    forced = world == 1 and args.force_collective
+    if forced:
+        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            # the communicator is bound to this rank's GPU before any collective runs
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                # the communicator is bound to this rank's GPU before any collective runs
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group(args.backend)
+            # the communicator itself is created by the first collective
+            dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=device))
+            torch.cuda.synchronize()
 
     K, M = args.k, args.max_total
     if args.scaling == "strong":
@@ -162,7 +190,7 @@ def main():
         if timers is not None or phases is not None:
             e1.record()
         # every rank sized its histograms for the same M; every bin count is at most total_rows
-        st.allreduce(same_extents=True, rows_bound=total_rows)
+        st.allreduce(same_extents=True, rows_bound=total_rows, force_message=forced)
         if phases is not None:
             e2 = ev()
             e2.record()
@@ -183,7 +211,7 @@ def main():
     # communicator is created (a tiny collective), so that even --warmup 0 times steady-state steps
     prime = dev.DeviceStats(K, M, M, device=device)
     prime.add_dense(X[:4096], max_count=M, max_total=M)
-    if world > 1:
+    if world > 1 or forced:
         dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=device))
     prime.check()
     del prime
@@ -205,7 +233,7 @@ def main():
         one_step()
 
     def barrier():
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -221,7 +249,7 @@ def main():
             outs = [one_step(timers) for _ in range(args.steps)]
             barrier()
         elapsed = time.perf_counter() - t_start
-        if world > 1:
+        if world > 1 or forced:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.cpu()[0])
@@ -283,7 +311,7 @@ def main():
                          % (K, total_rows, args.scaling, N, world, "" if world == 1 else "s", M,
                             "uint16" if esize == 2 else "int32")),
             "K": K, "rows_per_gpu": N, "rows_total": total_rows, "max_row_total": M,
-            "input_dtype": args.dtype, "backend": args.backend if world > 1 else None,
+            "input_dtype": args.dtype, "backend": args.backend if (world > 1 or forced) else None,
             "parallelism": "rows sharded x%d (contiguous blocks), one integer all-reduce, "
                            "replicated solve" % world,
         },
@@ -389,7 +417,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
     if not parity_ok:
         sys.stderr.write("bench.py: GPU alphas differ from the oracle's by %.3e relative (> %g)\n"

@@ -206,3 +206,57 @@ def test_compact_histogram_kernels_match_the_host_code(K, nbins, wider):
     back_d = parallel._from_compact(c_d, K, nb, off_d)
     assert torch.equal(back_d.cpu(), back_h)
     assert torch.equal(back_h.view(K, nb)[:, :nbins], hist) and not back_h.view(K, nb)[:, nbins:].any()
+
+
+def _nccl_one_rank(rank, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from bayespy_amd import device
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    rng = np.random.default_rng(3)
+    K, N = 300, 20000
+    X = (rng.integers(1, 40, size=(N, K)) * (rng.random((N, K)) < 0.05)).astype(np.uint16)
+    X[5, 7] = 900
+    Xd = torch.from_numpy(X).cuda()
+    res = {}
+    for name, kw in (("words64", {}), ("words32", {"same_extents": True, "rows_bound": N}),
+                     ("compact", {"compact": True, "rows_bound": N})):
+        pend = []
+        for _ in range(3):  # enqueued back to back, as bench.py does: no host wait in between
+            st = device.DeviceStats(K, 900, int(X.sum(axis=1).max()))
+            st.add_dense(Xd, max_count=900, max_total=int(X.sum(axis=1).max()))
+            st.allreduce(force_message=True, **kw)
+            pend.append(st.estimate_async(50))
+        outs = [p.result() for p in pend]
+        U, V = outs[-1]["uv"].to_lists()
+        res[name] = (U, V, outs[-1]["info"]["rows"], outs[-1]["alpha"], [o["n_iters"] for o in outs])
+    ref = device.DeviceStats(K, 900, int(X.sum(axis=1).max()))
+    ref.add_dense(Xd, max_count=900, max_total=int(X.sum(axis=1).max()))
+    o = ref.estimate_async(50).result()
+    U, V = o["uv"].to_lists()
+    res["plain"] = (U, V, o["info"]["rows"], o["alpha"], [o["n_iters"]] * 3)
+    out.update(res)
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_with_one_rank():
+    """The nccl (= RCCL) branch of the all-reduce on real hardware: a group of one rank, the message
+    forced through it (pack kernel -> RCCL all-reduce on the stream, no host wait -> unpack kernel ->
+    scan -> enqueued solve), three estimations in flight at a time, in all three message forms.  The
+    results are those of the same statistics without a collective."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_one_rank, args=(port, out), nprocs=1, join=True)
+    plain = out["plain"]
+    for name in ("words64", "words32", "compact"):
+        U, V, rows, alpha, iters = out[name]
+        assert U == plain[0] and V == plain[1] and rows == plain[2], name
+        assert np.array_equal(alpha, plain[3]) and iters == plain[4], name
