@@ -34,6 +34,10 @@ SIGNATURES = {
     "dme_bounds_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_bounds_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_bounds_csr_i32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "dme_dense_row_nnz_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_dense_row_nnz_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "dme_dense_to_csr_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "dme_dense_to_csr_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dme_stats_csr_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "dme_stats_csr_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64,
                                  _vp]),

@@ -347,11 +347,39 @@ class DeviceStats:
         self.reserve(max_count, max_total)
         with _on(self.device):
             ws, wsb = self._workspace(X.shape[0], X)
-            # rows wider than the dense kernels take (uint16: 32 768 columns, int32: 16 384) are
-            # refused with DME_ERR_UNSUPPORTED: such data belongs in add_csr
-            _lib.check(fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
-                          self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
-                          _ptr(self.status), ws, wsb, _stream()))
+            rc = fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
+                    self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
+                    _ptr(self.status), ws, wsb, _stream())
+            if rc == _lib.ERR_UNSUPPORTED:
+                # rows wider than the dense kernels take (uint16: 32 768 columns, int32: 16 384)
+                return self._add_dense_as_csr(X, max_count, max_total)
+            _lib.check(rc)
+        return self
+
+    def _add_dense_as_csr(self, X, max_count, max_total):
+        """Dense rows of more columns than the dense kernels take: compressed to CSR on the device
+        (dme_dense_row_nnz_* -> dme_shard_offsets -> dme_dense_to_csr_*, blocks of at most 2^30 cells)
+        and counted by the CSR entry.  One host read per block (the number of non-zero cells)."""
+        L = _lib.lib()
+        u16 = X.dtype == torch.uint16
+        nnz_fn = L.dme_dense_row_nnz_u16 if u16 else L.dme_dense_row_nnz_i32
+        csr_fn = L.dme_dense_to_csr_u16 if u16 else L.dme_dense_to_csr_i32
+        step = max(1, (1 << 30) // max(self.K, 1))
+        with _on(self.device):
+            for lo in range(0, X.shape[0], step):
+                blk = X[lo:lo + step]
+                n = blk.shape[0]
+                counts = torch.empty(n, dtype=torch.int64, device=self.device)
+                rowptr = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+                _lib.check(nnz_fn(blk.data_ptr(), n, self.K, blk.stride(0), _ptr(counts), _stream()))
+                _lib.check(L.dme_shard_offsets(_ptr(counts), n, _ptr(rowptr), _stream()))
+                nnz = int(rowptr[n].cpu())
+                colidx = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)[:nnz]
+                vals = torch.empty(max(nnz, 1), dtype=torch.int32, device=self.device)[:nnz]
+                if nnz:
+                    _lib.check(csr_fn(blk.data_ptr(), n, self.K, blk.stride(0), _ptr(rowptr),
+                                      _ptr(colidx), _ptr(vals), _stream()))
+                self.add_csr(rowptr, colidx, vals, max_count=max_count, max_total=max_total)
         return self
 
     def add_csr(self, rowptr, colidx, vals, max_count=None, max_total=None):

@@ -106,6 +106,23 @@ int dme_stats_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_
                         int64_t tbins, double* init_acc /*[dev]*/, uint64_t* status /*[dev]*/,
                         void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
 
+/* Dense rows wider than the entries above take: compress them to CSR on the device and use
+ * dme_stats_csr_i32.  dme_dense_row_nnz_* writes counts[i] = the non-zero cells of row i;
+ * dme_shard_offsets(counts, N, rowptr) turns them into rowptr[N + 1] (rowptr[N] = nnz, which the caller
+ * reads back to size colidx / vals); dme_dense_to_csr_* fills colidx / vals (columns ascending
+ * within a row; negative cells are kept and reported by the CSR pass).  No counterpart in the
+ * reference, whose appendRow takes rows of any length (DE/dme.py:113-123). */
+int dme_dense_row_nnz_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                          int64_t* counts /*[dev][N] out*/, void* stream);
+int dme_dense_row_nnz_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                          int64_t* counts /*[dev][N] out*/, void* stream);
+int dme_dense_to_csr_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                         const int64_t* rowptr /*[dev][N+1]*/, int32_t* colidx /*[dev][nnz] out*/,
+                         int32_t* vals /*[dev][nnz] out*/, void* stream);
+int dme_dense_to_csr_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
+                         const int64_t* rowptr /*[dev][N+1]*/, int32_t* colidx /*[dev][nnz] out*/,
+                         int32_t* vals /*[dev][nnz] out*/, void* stream);
+
 /* CSR rows (rowptr int64[N+1], colidx int32[nnz], vals int32[nnz]); same outputs.  Entries with
  * value 0 are legal and ignored, as a zero count is in DE/dme.py:117.
  * With a workspace of dme_stats_csr_workspace_bytes(N, nnz, K) bytes (256-byte aligned; it holds

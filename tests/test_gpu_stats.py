@@ -310,12 +310,69 @@ def test_staged_rows_in_several_rounds(oracle):
                                          torch.cuda.current_stream().cuda_stream))
 
 
-def test_rows_beyond_the_dense_range_are_refused():
+@pytest.mark.parametrize("K,dtype", [(40000, "u16"), (20000, "i32"), (50000, "i32")])
+def test_rows_beyond_the_dense_range_go_through_csr(oracle, K, dtype):
+    """Dense rows of more columns than the dense kernels take are compressed to CSR by HIP kernels
+    (no torch compute) and counted by the CSR entry: same statistics as the oracle.  The C entry
+    itself refuses them (DME_ERR_UNSUPPORTED)."""
+    from bayespy_amd import _lib
     dev = _dev()
-    for K, dt in ((32776, torch.uint16), (16392, torch.int32)):
-        st = dev.DeviceStats(K)
-        with pytest.raises(NotImplementedError, match="CSR"):
-            st.add_dense(torch.zeros((4, K), dtype=dt, device="cuda"), max_count=1, max_total=1)
+    rng = np.random.default_rng(K)
+    N = 300
+    X = rng.integers(1, 30, size=(N, K)) * (rng.random((N, K)) < 0.004)
+    X[0, 0], X[N - 1, K - 1], X[7] = 3, 4, 0
+    X[5, 100] = 500
+    npdt = np.uint16 if dtype == "u16" else np.int32
+    Xd = torch.from_numpy(X.astype(npdt)).cuda()
+    st = dev.DeviceStats(K)
+    L = _lib.lib()
+    fn = L.dme_stats_dense_u16 if dtype == "u16" else L.dme_stats_dense_i32
+    ws = torch.empty(L.dme_stats_workspace_bytes(N, K) + 256, dtype=torch.uint8, device="cuda")
+    rc = fn(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins, st.histV.data_ptr(), st.tbins,
+            st.init_acc.data_ptr(), st.status.data_ptr(), ws.data_ptr() + (-ws.data_ptr()) % 256,
+            ws.numel() - 256, torch.cuda.current_stream().cuda_stream)
+    assert rc == _lib.ERR_UNSUPPORTED
+    st.add_dense(Xd)
+    info = st.check()
+    assert info["rows"] == N and info["max_count"] == 500
+    ref = oracle.append_rows(X.astype(npdt))
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+    # the conversion itself: row pointers, ascending columns, values
+    counts = torch.empty(N, dtype=torch.int64, device="cuda")
+    rowptr = torch.empty(N + 1, dtype=torch.int64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    nz = L.dme_dense_row_nnz_u16 if dtype == "u16" else L.dme_dense_row_nnz_i32
+    cv = L.dme_dense_to_csr_u16 if dtype == "u16" else L.dme_dense_to_csr_i32
+    _lib.check(nz(Xd.data_ptr(), N, K, K, counts.data_ptr(), s))
+    _lib.check(L.dme_shard_offsets(counts.data_ptr(), N, rowptr.data_ptr(), s))
+    nnz = int(rowptr[N].cpu())
+    colidx = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    vals = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    _lib.check(cv(Xd.data_ptr(), N, K, K, rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), s))
+    rr, cc = np.nonzero(X)
+    assert nnz == len(rr)
+    assert np.array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.count_nonzero(X, axis=1))]))
+    assert np.array_equal(colidx.cpu().numpy(), cc) and np.array_equal(vals.cpu().numpy(), X[rr, cc])
+
+
+def test_module_surface_takes_rows_of_a_wide_vocabulary():
+    """The drop-in's appendRow with K beyond the dense kernels' range (BASELINE configs[3] has
+    K = 50 000): rows are buffered dense and reach the GPU through the CSR conversion."""
+    import bayespy_amd.dirichletMultinomialEstimation as DME
+    rng = np.random.default_rng(77)
+    K = 20000
+    data = DME.CompressedRowData(K)
+    rows = []
+    for _ in range(40):
+        row = np.zeros(K, dtype=np.int64)
+        row[rng.integers(0, K, 30)] = rng.integers(1, 5, 30)
+        rows.append(row)
+        data.appendRow(row.tolist(), 1)
+    X = np.stack(rows)
+    assert [int(v) for v in data.V] == [int((X.sum(axis=1) > n).sum()) for n in range(int(X.sum(axis=1).max()))]
+    k = int(np.argmax(X.max(axis=0)))
+    assert [int(u) for u in data.U[k]] == [int((X[:, k] > n).sum()) for n in range(int(X[:, k].max()))]
 
 
 def _csr_direct(dev, rowptr, colidx, vals, K, nbins, tbins, partitioned):
