@@ -636,6 +636,42 @@ def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
     assert int(uv.Vi[0]) == N
 
 
+@pytest.mark.parametrize("K,N,dtype", [(3000, 400_000, "u16"), (8192, 200_000, "u16"), (16384, 60_000, "u16"),
+                                       (32768, 40_000, "u16"), (2048, 300_000, "i32"), (4096, 200_000, "i32"),
+                                       (8192, 80_000, "i32"), (16384, 40_000, "i32"), (6001, 90_000, "u16")])
+def test_long_rows_at_size_against_torch_reductions(K, N, dtype):
+    """Rows shared by teams of waves (and K = 3000: six vectors per lane; K = 6001: staged, then a
+    team) over enough rows that every workgroup runs many loop steps of the interleaved / slab
+    mappings: row count, column sums, grand total and the row-total histogram against torch
+    reductions (size-independent properties; the small shapes are compared with the oracle cell by
+    cell in test_wide_and_staged_rows_bit_exact_vs_oracle)."""
+    dev = _dev()
+    rng = np.random.default_rng(K)
+    alpha = 0.002 + rng.gamma(2.0, 0.01, size=K)
+    max_total = 400
+    totals = torch.randint(1, max_total + 1, (N,), dtype=torch.int32, device="cuda",
+                           generator=torch.Generator(device="cuda").manual_seed(K))
+    X = dev.synth_dirmult(N, K, alpha, totals, seed=78,
+                          dtype=torch.uint16 if dtype == "u16" else torch.int32)
+    st = dev.DeviceStats(K)
+    st.add_dense(X, max_count=max_total, max_total=max_total)
+    assert st.check()["rows"] == N
+    uv = st.finalize()
+    U = uv.Ui.view(K, uv.ldU)
+    colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
+    step = max(1, (64 << 20) // K)
+    for lo in range(0, N, step):
+        blk = X[lo:lo + step]
+        if dtype == "u16":
+            blk = blk.view(torch.int16).to(torch.int64).bitwise_and(0xFFFF)
+        colsum += blk.to(torch.int64).sum(dim=0)
+    assert torch.equal(U.sum(dim=1), colsum)
+    assert int(colsum.sum()) == int(totals.to(torch.int64).sum())
+    assert torch.equal(st.histV[:max_total + 1],
+                       torch.bincount(totals.to(torch.int64), minlength=max_total + 1))
+    assert int(uv.Vi[0]) == N
+
+
 @pytest.mark.parametrize("K,dtype,big", [(16, "u16", 0), (2, "i32", 0), (24, "u16", 0), (16, "u16", 700),
                                          (8, "u16", 500), (2, "i32", 100_000)])
 def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype, big):
