@@ -222,6 +222,33 @@ __device__ __forceinline__ void block_reduce_fused(DmeAcc (&a)[NA], double (&d)[
     __syncthreads();
 }
 
+// The same without compensated sums (same order of additions as block_reduce_fused's plain sums).
+template <int ND>
+__device__ __forceinline__ void block_reduce_plain(double (&d)[ND], bool& flag, BlockShared& sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = dme_wave_sum_f64(d[i]);
+    const int any = __any(flag);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) sh.fdbl[i][wave] = d[i];
+        sh.fflag[wave] = any;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        double r = sh.fdbl[i][0];
+#pragma unroll
+        for (int w = 1; w < STEP_WAVES; ++w) r = __dadd_rn(r, sh.fdbl[i][w]);
+        d[i] = r;
+    }
+    int f = 0;
+#pragma unroll
+    for (int w = 0; w < STEP_WAVES; ++w) f |= sh.fflag[w];
+    flag = f != 0;
+    __syncthreads();
+}
+
 // Block minimum, returned to every thread (used off the hot path only).
 __device__ double block_min_f64(double x, BlockShared& sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -443,7 +470,9 @@ __device__ __forceinline__ void gather_prefetch(const EvalArgs& e, const Partial
     long long lv = e.lenV[0];
     pf.LV = lv > e.capV ? e.capV : lv;
     pf.pv = PartV{{0, 0, 0, 0, 0}};
-    if (tid < SV) pf.pv = ld_part(part + K * S + tid);
+    // up to 64 slots: every wave holds them all, one per lane (gather_eval sums them inside the wave)
+    const long long vslot = SV <= 64 ? (long long)(tid & 63) : (long long)tid;
+    if (vslot < SV) pf.pv = ld_part(part + K * S + vslot);
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
         const long long k = tid + (long long)c * STEP_BLOCK;
@@ -482,16 +511,32 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
         const long long nv = LV > 0 ? (LV + SEG - 1) / SEG : 0;
         DmeAcc a[2] = {{0, 0}, {0, 0}};
         double d[1] = {0.0};
-        for (long long i = tid; i < nv; i += STEP_BLOCK) {
-            PartV p;
-            if constexpr (NCOL > 0) p = pf->pv;  // SV <= STEP_BLOCK: i == tid
-            else p = ld_part(w.part + K * S + i);
-            a[0].add(DmeAcc{p.v[0], p.v[1]});
-            a[1].add(DmeAcc{p.v[2], p.v[3]});
-            d[0] = __dadd_rn(d[0], p.v[4]);
+        if (slots_per_column(e.capV) <= 64) {
+            // Up to 64 slots (row totals below 16 384: every BASELINE configuration but the heavy
+            // tail): each wave adds them all by itself, a slot per lane, in the order of the wave
+            // sum - no LDS, no barrier.  (The block reduction below gives the same bits: its other
+            // waves add zeros.  It costs 1.3 us of the step's critical path, this 0.4.)
+            const int lane = tid & 63;
+            PartV p{{0, 0, 0, 0, 0}};
+            if (lane < nv) {
+                if constexpr (NCOL > 0) p = pf->pv;
+                else p = ld_part(w.part + K * S + lane);
+            }
+            a[0] = dme_wave_sum_acc(DmeAcc{p.v[0], p.v[1]});
+            a[1] = dme_wave_sum_acc(DmeAcc{p.v[2], p.v[3]});
+            d[0] = dme_wave_sum_f64(p.v[4]);
+        } else {
+            for (long long i = tid; i < nv; i += STEP_BLOCK) {
+                PartV p;
+                if constexpr (NCOL > 0) p = pf->pv;  // SV <= STEP_BLOCK: i == tid
+                else p = ld_part(w.part + K * S + i);
+                a[0].add(DmeAcc{p.v[0], p.v[1]});
+                a[1].add(DmeAcc{p.v[2], p.v[3]});
+                d[0] = __dadd_rn(d[0], p.v[4]);
+            }
+            bool none = false;
+            block_reduce_fused<2, 1>(a, d, none, sh);
         }
-        bool none = false;
-        block_reduce_fused<2, 1>(a, d, none, sh);
         G.t0 = a[0];
         G.t1 = a[1];
         G.t2 = d[0];
@@ -642,7 +687,6 @@ __device__ bool logspace_trial(const double* alpha, const double* g, const doubl
 // trial is valid (every alpha > 0) to every thread
 __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, BlockShared& sh) {
     const int tid = threadIdx.x;
-    DmeAcc none[1] = {{0, 0}};
     double a[1] = {0.0};
     bool bad = false;
     for (long long k = tid; k < K; k += STEP_BLOCK) {
@@ -650,7 +694,7 @@ __device__ bool finish_trial(Ctrl* ctrl, const double* trial, long long K, Block
         a[0] = __dadd_rn(a[0], t);
         if (t <= 0.0) bad = true;
     }
-    block_reduce_fused<1, 1>(none, a, bad, sh);
+    block_reduce_plain<1>(a, bad, sh);
     if (tid == 0) {
         ctrl->A_trial = a[0];
         ctrl->trial_valid = bad ? 0 : 1;
@@ -702,6 +746,13 @@ struct LazyCur {
     const double* d_cur;
 };
 
+#ifdef DME_SOLVE_TS
+__device__ long long g_dbg[16];
+#define DBG_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DBG_TS(i)
+#endif
+
 template <bool CPT, int NCOL = 0>
 __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long iterations,
                           const Prior& pr, double* trace, double* trace_alpha, long long trace_cap,
@@ -727,9 +778,12 @@ __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long
     double lossT = INFINITY;
     double hconstT = 0.0;
     Gathered G{};
+    DBG_TS(0);
     if (valid) {
         G = gather_eval<CPT, NCOL>(w, e, K, A, pr, w.alpha_trial, w.g_trial, w.d_trial, sh, pf);
+        DBG_TS(1);
         lossT = loss_from<CPT>(G, A, pr);
+        DBG_TS(2);
         hconstT = G.t2;
         n_evals += 1;
         // SURVEY 7 "parity-fragile": the comparisons of DE/dme.py:160 / :176 are about to be taken on
@@ -859,6 +913,7 @@ __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long
         if (tid == 0) c->hconst_cur = hconstT;
     }
     const double hconst = hconstT;  // == hconst_cur after an accept
+    DBG_TS(3);
 
     // ---- top of the while loop, DE/dme.py:137-150 ---------------------------------------------
     if (count >= iterations) {  // :137 / :189-190
@@ -880,6 +935,7 @@ __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long
         finish(1, 0);
         return;
     }
+    DBG_TS(4);
     // getPredictedStep (:67-72) from the sums gathered with the evaluation
     if (G.zero_d || hconst == 0.0) { finish(0, DME_ERR_ZERO_DIVISION); return; }
     const double dd = __dadd_rn(__ddiv_rn(1.0, hconst), G.denSum);
@@ -887,7 +943,9 @@ __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long
     const double bb = __ddiv_rn(G.numSum, dd);
     for (long long k = tid; k < K; k += STEP_BLOCK)
         w.alpha_trial[k] = __dadd_rn(w.alpha_cur[k], __ddiv_rn(__dsub_rn(bb, w.g_cur[k]), w.d_cur[k]));
+    DBG_TS(5);
     finish_trial(c, w.alpha_trial, K, sh);
+    DBG_TS(6);
     store_state(PH_NEWTON);
 }
 
@@ -961,6 +1019,9 @@ struct IterArgs {
     const double* init_acc;    // launch 0: CLI start point from the mean accumulators, or NULL
     const u64* status;         // launch 0: copied to result[8..16), or NULL
     int parity, first;
+#ifdef DME_SOLVE_TS
+    int launch;
+#endif
 };
 
 template <bool CPT, int NCOL>
@@ -973,6 +1034,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
     const int parity = a.parity;
     const bool first = a.first != 0;
     const bool writer = blockIdx.x == 0;
+#ifdef DME_SOLVE_TS
+    long long ts[6];
+    ts[0] = wall_clock64();
+#define TS(i) ts[i] = wall_clock64()
+#else
+#define TS(i)
+#endif
     const Ctrl* cin = parity ? w.ctrl2 : w.ctrl;
     Ctrl* cout = parity ? w.ctrl : w.ctrl2;
     const Partial* part_in = parity ? w.part2 : w.part;
@@ -1021,6 +1089,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
         for (long long k = tid; k < K; k += STEP_BLOCK) l_atr[k] = in_atr[k];
         const LazyCur lz{in_acur, in_gcur, in_dcur};
         __syncthreads();
+        TS(1);
         if (lc.done) {  // uniform over the grid: the solve ended in an earlier launch
             if (writer && tid == 0) cout->done = 1;  // the launch after this one reads `cout`
             return;
@@ -1038,6 +1107,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
                              a.result, a.final_loss, sh, writer, NCOL > 0 ? &gpf : nullptr, &lz);
     }
     __syncthreads();
+    TS(2);
     if (writer) {
         if (tid < (int)(sizeof(Ctrl) / 8)) ((long long*)cout)[tid] = ((const long long*)&lc)[tid];
         double* o_acur = parity ? w.alpha_cur : w.alpha_cur2;
@@ -1055,7 +1125,22 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
     }
     // the evaluation of the new trial point (nothing to do once done, or for a trial with an
     // alpha <= 0, which scores inf without an evaluation: eval_segments checks both)
+    TS(3);
     eval_segments(&lc, e, K, l_atr, part_out, wave0, (long long)gridDim.x * STEP_WAVES, &epf);
+    TS(4);
+#ifdef DME_SOLVE_TS
+    if (blockIdx.x == 0 && tid == 0 && a.launch < 20 && a.trace_cap >= 45) {
+        double* o = a.trace + (long long)(22 + a.launch) * 4;
+        o[0] = (double)(ts[1] - ts[0]);
+        o[1] = (double)(ts[2] - ts[1]);
+        o[2] = (double)(ts[3] - ts[2]);
+        o[3] = (double)(ts[4] - ts[3]);
+        if (a.launch == 5) {
+            double* q = a.trace + 40 * 4;
+            for (int i = 0; i < 6; ++i) q[i] = (double)(g_dbg[i + 1] - g_dbg[i]);
+        }
+    }
+#endif
 }
 
 // dme_eval epilogue: publish the evaluated quantities
@@ -1396,7 +1481,11 @@ int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first,
             ncol = c.K <= STEP_BLOCK ? 1 : (c.K <= 2 * STEP_BLOCK ? 2 : 4);
         for (long long j = first; j < first + count; ++j) {
             const IterArgs a{c.K, c.iterations, c.trace, c.trace_alpha, c.trace_cap, c.alpha, c.result,
-                             c.final_loss, c.init_acc, c.status, (int)(j & 1), j == 0 ? 1 : 0};
+                             c.final_loss, c.init_acc, c.status, (int)(j & 1), j == 0 ? 1 : 0
+#ifdef DME_SOLVE_TS
+                             , (int)j
+#endif
+            };
             const int rc = cpt ? launch_iter_ncol<true>(ncol, w, ea, c.pr, a, (unsigned)fg, lds, s)
                                : launch_iter_ncol<false>(ncol, w, ea, c.pr, a, (unsigned)fg, lds, s);
             if (rc) return rc;

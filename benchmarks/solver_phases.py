@@ -1,0 +1,23 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
+import numpy as np, torch
+from bayespy_amd import _lib
+_lib.LIB_PATH = os.path.abspath("bayespy_amd/libdme_ts.so")
+from bayespy_amd import device as dev
+K, N, M = 1000, 2_000_000, 500
+rng = np.random.default_rng(0)
+alpha = 0.01 + rng.gamma(2.0, 0.05, size=K)
+tot = torch.randint(1, M + 1, (N,), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+X = dev.synth_dirmult(N, K, alpha, tot, seed=3)
+for rep in range(3):
+    st = dev.DeviceStats(K, M, M)
+    st.add_dense(X, max_count=M, max_total=M)
+    p = st.estimate_async(50)
+    out = p.result()
+    tr = p.buf[16:].view(p.cap, 4)[22:22 + 14].cpu().numpy() * 10.0  # ns
+    fine = p.buf[16:].view(p.cap, 4)[40:42].cpu().numpy().reshape(-1)[:6] * 10.0
+print("iters", out["n_iters"], "evals", out["n_evals"])
+print("step_body of launch 5 (ns): gather_eval, loss_from, accept copy, trace+checks, trial, finish_trial:", fine)
+print("launch: load+sync  step_body  writer_store  eval   (ns)")
+for i, r in enumerate(tr):
+    print(i, r)
