@@ -1,3 +1,13 @@
+#!/usr/bin/env python3
+"""Where one launch of the solver (iter_kernel, K <= 2048) spends its time.
+
+Needs a build of the library with time stamps compiled in (never the shipped one):
+    make -C bayespy_amd/csrc ts          # -> bayespy_amd/libdme_ts.so  (-DDME_SOLVE_TS)
+    python benchmarks/solver_phases.py
+Thread 0 of workgroup 0 reads s_memrealtime (10 ns) at the phase boundaries of every launch and
+leaves the differences in unused rows of the trace buffer; printed per launch: state and partial
+sums loaded, step_body, state stored by workgroup 0, evaluation of the new trial point; and the
+pieces of step_body for launch 5."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import numpy as np, torch
