@@ -63,8 +63,14 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
     const long long row1 = row0 + a.rows_per_wg < a.N ? row0 + a.rows_per_wg : a.N;
     u64 bad_cells = 0, bad_rows = 0, neg = 0;
     constexpr int JR = J > 0 ? J : 1;
-    int cur[JR], nxt[JR];
-    auto load_row = [&](int (&d)[JR], long long i) {
+    // Rows in flight per wave: a row of K = 100 int32 cells is 400 bytes, and with one row ahead the
+    // whole chip had 1.6 MB outstanding - the pass waited for memory latency, once for the row and
+    // once more for its weights, which were fetched when first used.  DEPTH rows and their weights
+    // (lane c holds weight c of the row) are loaded ahead now.
+    constexpr int DEPTH = J > 0 ? (J <= 4 ? 4 : 2) : 1;
+    int rowbuf[DEPTH][JR];
+    double wbuf[DEPTH];
+    auto load_row = [&](int (&d)[JR], double& wv, long long i) {
         if constexpr (J > 0) {
             const int* row = a.X + i * a.ld;
 #pragma unroll
@@ -72,22 +78,34 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
                 const long long k = lane + 64 * j;
                 d[j] = (i < row1 && k < K) ? __builtin_nontemporal_load(row + k) : 0;
             }
+            wv = (i < row1 && lane < C) ? a.wts[i * C + lane] : 0.0;
         }
     };
-    auto total_of = [&](u64 total, const double* w) {
-        if (lane == 0 && total > 0) {
+    // weight c of the row in hand: from the lane that holds it (wv), or from memory (J == 0)
+    struct Wts {
+        const double* p;
+        double v;
+        __device__ __forceinline__ double operator[](long long c) const {
+            return p ? p[c] : dme_readlane_f64(v, (int)c);
+        }
+    };
+    auto total_of = [&](u64 total, const Wts& w) {
+        if (total > 0) {  // wave-uniform
             if ((long long)total < a.tbins) {
-                atomicMax(&sh_stat[5], total);
-                if (total < (u64)TB)
-                    for (long long c = 0; c < C; ++c) atomicAdd(&hv[c * TB + (long long)total], w[c]);
-                else
-                    for (long long c = 0; c < C; ++c) atomicAdd(&a.histVW[c * a.tbins + (long long)total], w[c]);
-            } else {
+                if (lane == 0) atomicMax(&sh_stat[5], total);
+                for (long long c = 0; c < C; ++c) {
+                    const double wc = w[c];
+                    if (lane == 0) {
+                        if (total < (u64)TB) atomicAdd(&hv[c * TB + (long long)total], wc);
+                        else atomicAdd(&a.histVW[c * a.tbins + (long long)total], wc);
+                    }
+                }
+            } else if (lane == 0) {
                 bad_rows++;
             }
         }
     };
-    auto cell = [&](int v, long long k, const double* w) {
+    auto cell = [&](int v, long long k, const Wts& w) {
         if (v == 0) return;
         if (v < 0) { neg++; return; }
         if ((long long)v >= a.nbins) { bad_cells++; return; }
@@ -101,20 +119,40 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
         else
             for (long long c = 0; c < C; ++c) atomicAdd(&a.histW[(c * K + k) * a.nbins + v], w[c]);
     };
-    load_row(nxt, row0 + wave);
-    for (long long i = row0 + wave; i < row1; i += WWAVES) {
-        const double* w = a.wts + i * C;
+    if constexpr (J > 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load_row(rowbuf[d], wbuf[d], row0 + wave + (long long)d * WWAVES);
+    }
+    for (long long i0 = row0 + wave; i0 < row1; i0 += (long long)WWAVES * DEPTH) {
         if constexpr (J > 0) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) cur[j] = nxt[j];
-            load_row(nxt, i + WWAVES);
-            u64 s = 0;
+            for (int d = 0; d < DEPTH; ++d) {
+                const long long i = i0 + (long long)d * WWAVES;
+                if (i < row1) {  // wave-uniform
+                    int cur[JR];
 #pragma unroll
-            for (int j = 0; j < J; ++j) s += (u64)(cur[j] > 0 ? cur[j] : 0);
-            total_of(dme_wave_sum_u64(s), w);
+                    for (int j = 0; j < J; ++j) cur[j] = rowbuf[d][j];
+                    const Wts w{nullptr, wbuf[d]};
+                    load_row(rowbuf[d], wbuf[d], i + (long long)WWAVES * DEPTH);
+                    u32 m = 0;
+                    u64 s = 0;
 #pragma unroll
-            for (int j = 0; j < J; ++j) cell(cur[j], lane + 64 * j, w);
+                    for (int j = 0; j < J; ++j) {
+                        const u32 pos = cur[j] > 0 ? (u32)cur[j] : 0u;
+                        m |= pos;
+                        s += pos;
+                    }
+                    // 64 lanes x J cells below 2^20 cannot wrap 32 bits: the DPP sum
+                    const u64 total = __any(m >= (1u << 20)) ? dme_wave_sum_u64(s)
+                                                            : (u64)dme_wave_sum_u32((u32)s);
+                    total_of(total, w);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) cell(cur[j], lane + 64 * j, w);
+                }
+            }
         } else {
+            const long long i = i0;
+            const Wts w{a.wts + i * C, 0.0};
             const int* row = a.X + i * a.ld;
             u64 s = 0;
             for (long long k = lane; k < K; k += 64) {
