@@ -486,6 +486,13 @@ __device__ __forceinline__ void gather_prefetch(const EvalArgs& e, const Partial
     }
 }
 
+#ifdef DME_SOLVE_TS
+__device__ long long g_dbg[16];
+#define DBG_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DBG_TS(i)
+#endif
+
 // Per-column sums at the evaluated point -> g_out[k], d_out[k]; returns the block totals.
 // Two fused block reductions: the V sums first (the gradient needs them), then everything per k.
 // CPT = false compiles the (Beta, W) terms out, so the scalar-hyperprior kernels keep their
@@ -541,6 +548,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
         G.t1 = a[1];
         G.t2 = d[0];
     }
+    DBG_TS(8);
     double psiA = 0.0;
     if (CPT && pr.has_W) {
         G.t2 = __dadd_rn(G.t2, __dmul_rn(pr.W, dme_trigamma(A)));  // CPT/dme.py:74-75
@@ -602,7 +610,9 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
             column(k, a0, a1, a2);
         }
     }
+    DBG_TS(9);
     block_reduce_fused<1, NR>(ls, r, zero, sh);
+    DBG_TS(10);
     G.logsum = ls[0];
     G.gradSq = r[0];
     G.numSum = r[1];
@@ -745,13 +755,6 @@ struct LazyCur {
     const double* g_cur;
     const double* d_cur;
 };
-
-#ifdef DME_SOLVE_TS
-__device__ long long g_dbg[16];
-#define DBG_TS(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_dbg[i] = wall_clock64(); } while (0)
-#else
-#define DBG_TS(i)
-#endif
 
 template <bool CPT, int NCOL = 0>
 __device__ void step_body(const Ws& w, const EvalArgs& e, long long K, long long iterations,
@@ -1138,6 +1141,9 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
         if (a.launch == 5) {
             double* q = a.trace + 40 * 4;
             for (int i = 0; i < 6; ++i) q[i] = (double)(g_dbg[i + 1] - g_dbg[i]);
+            q[6] = (double)(g_dbg[8] - g_dbg[0]);
+            q[7] = (double)(g_dbg[9] - g_dbg[8]);
+            q[8] = (double)(g_dbg[10] - g_dbg[9]);
         }
     }
 #endif

@@ -25,9 +25,9 @@ for rep in range(3):
     p = st.estimate_async(50)
     out = p.result()
     tr = p.buf[16:].view(p.cap, 4)[22:22 + 14].cpu().numpy() * 10.0  # ns
-    fine = p.buf[16:].view(p.cap, 4)[40:42].cpu().numpy().reshape(-1)[:6] * 10.0
+    fine = p.buf[16:].view(p.cap, 4)[40:43].cpu().numpy().reshape(-1)[:9] * 10.0
 print("iters", out["n_iters"], "evals", out["n_evals"])
-print("step_body of launch 5 (ns): gather_eval, loss_from, accept copy, trace+checks, trial, finish_trial:", fine)
+print("step_body of launch 5 (ns): gather_eval, loss_from, accept copy, trace+checks, trial, finish_trial | inside gather_eval: V sums, columns, block reduction:", fine)
 print("launch: load+sync  step_body  writer_store  eval   (ns)")
 for i, r in enumerate(tr):
     print(i, r)
