@@ -106,3 +106,39 @@ def test_config4_bag_of_words_csr(oracle):
     ref = oracle.find_priors(ref_st, a0.cpu().numpy(), 50, 0.0)
     np.testing.assert_allclose(out["alpha"], ref["alpha"], rtol=1e-9)
     assert out["n_iters"] == ref["n_iters"]
+
+
+def test_regression_callers_start_point_at_scale(oracle):
+    """DirichletRegression/dirichletRegression.py:137-141 takes its baseline prior
+    from findDirichletPriors(data, [1.0] * K, 50) - a start far from the optimum, which walks the
+    fallback branches (log-space trials, the x0.9 loop) before Newton steps take over.  The drop-in
+    module on 1 M rows of K = 200 against the oracle on the same U/V: same alphas to 1e-9, same
+    exit, and - when no decision was taken on rounding noise - the same iteration and evaluation
+    counts and the same logged loss at every iteration."""
+    import bayespy_amd.dirichletMultinomialEstimation as DME
+    from bayespy_amd import device
+    K, N = 200, 1_000_000
+    rng = np.random.default_rng(5)
+    alpha_true = 0.02 + rng.gamma(2.0, 0.1, size=K)
+    totals = torch.randint(1, 301, (N,), dtype=torch.int32, device="cuda",
+                           generator=torch.Generator(device="cuda").manual_seed(5))
+    X = device.synth_dirmult(N, K, alpha_true, totals, seed=20260006)
+    data = DME.CompressedRowData(K)
+    data.appendDevice(X, max_count=300, max_total=300)
+    priors = DME.findDirichletPriors(data, [1.0] * K, 50)
+    st = data.deviceStats()
+    uv = st.finalize()
+    out = uv.solve(torch.ones(K, dtype=torch.float64, device="cuda"), 50, 0.0)
+    np.testing.assert_array_equal(np.asarray(priors), out["alpha"])  # the module is this call
+    Ul, Vl = uv.to_lists()
+    full = oracle.stats_from_lists(Ul, Vl)
+    ref = oracle.find_priors(full, np.ones(K), 50, 0.0)
+    np.testing.assert_allclose(out["alpha"], ref["alpha"], rtol=1e-9)
+    assert {1: "A", 2: "B", 3: "C"}[out["exit"]] == ref["exit"]
+    assert out["n_evals"] > out["n_iters"]  # the fallback branches were walked
+    if out["fragile_decisions"] == 0:
+        assert out["n_iters"] == ref["n_iters"] and out["n_evals"] == ref["n_evals"]
+        # the loss and the squared gradient the reference logs at the top of every iteration
+        np.testing.assert_allclose(out["trace"][:, 0], ref["trace_loss"], rtol=1e-12)
+        # (at the optimum the gradient is what cancellation leaves of terms ~1e6: absolute bound)
+        np.testing.assert_allclose(out["trace"][:, 1], ref["trace_gradsq"], rtol=1e-6, atol=1e-11)
