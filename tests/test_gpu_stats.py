@@ -279,6 +279,41 @@ def test_wide_and_staged_rows_bit_exact_vs_oracle(oracle, N, K, ld, dtype):
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_dense_layouts_fuzz_vs_oracle(oracle, seed):
+    """Random shapes through the dense entry: any K up to the team range, any pitch, any element
+    offset of the base pointer, both element types - whichever kernel the plan picks (vectors of 1
+    to 8 elements, 1 to 8 of them per lane, side-by-side rows, packed int32, teams, staging), the
+    statistics are the oracle's."""
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    dtype = "u16" if seed % 2 == 0 else "i32"
+    kmax = 9000 if dtype == "u16" else 5000
+    K = int(rng.choice([rng.integers(1, 70), rng.integers(70, 600), rng.integers(600, kmax)]))
+    if seed % 6 == 0:
+        K = (K + 7) // 8 * 8  # the aligned layouts too
+    pad = int(rng.choice([0, 0, 1, 3, 8, 24]))
+    off = int(rng.choice([0, 0, 0, 1, 2, 4]))
+    N = int(rng.integers(1, 400))
+    ld = K + pad
+    density = float(rng.choice([0.02, 0.2, 0.9]))
+    big = rng.integers(1, 40, size=(N, ld)) * (rng.random((N, ld)) < density)
+    for _ in range(4):
+        big[rng.integers(0, N), rng.integers(0, K)] = int(rng.integers(100, 60000))
+    npdt = np.uint16 if dtype == "u16" else np.int32
+    flat = torch.zeros(N * ld + 16, dtype=torch.uint16 if dtype == "u16" else torch.int32, device="cuda")
+    flat[off:off + N * ld] = torch.from_numpy(big.astype(npdt).reshape(-1)).cuda()
+    view = flat[off:off + N * ld].view(N, ld)[:, :K]
+    st = dev.DeviceStats(K)
+    st.add_dense(view)
+    info = st.check()
+    X = big[:, :K]
+    assert info == {"rows": N, "max_count": int(X.max()), "max_total": int(X.sum(axis=1).max())}
+    ref = oracle.append_rows(X.astype(npdt))
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
+
+
 def test_staged_rows_in_several_rounds(oracle):
     """A staging area that holds a part of the rows only: the rounds add up."""
     from bayespy_amd import _lib
