@@ -238,3 +238,37 @@ def test_enqueued_estimate_reports_data_errors():
     st.add_dense(Z)
     with pytest.raises(ZeroDivisionError):
         st.estimate_async(50, 0.0).result()
+
+
+@pytest.mark.parametrize("top", [16383, 16384, 16385, 16700, 40000])
+def test_row_totals_around_the_wave_sum_limit(oracle, top):
+    """The V partial sums are added inside every wave while they fit one (64 slots of 256 totals:
+    row totals up to 16 384) and by the block reduction beyond: the same results either side of the
+    limit, on all three launch structures, against the oracle."""
+    from bayespy_amd import _lib, device
+    rng = np.random.default_rng(top)
+    K, N = 6, 3000
+    p = rng.dirichlet(np.full(K, 0.7), size=N)
+    totals = rng.integers(1, top + 1, size=N)
+    totals[0] = top
+    X = np.stack([rng.multinomial(int(t), q) for t, q in zip(totals, p)]).astype(np.int32)
+    st = device.DeviceStats(K)
+    st.add_dense(torch.from_numpy(X).cuda())
+    assert st.check()["max_total"] == top
+    uv = st.finalize()
+    ref_st = oracle.append_rows(X)
+    ref = oracle.find_priors(ref_st, ref_st.cli_init_alphas(), 50, 0.0)
+    L = _lib.lib()
+    outs = []
+    try:
+        for path in (2, 1, 3):  # single launch, launch pairs, one launch per evaluation
+            _lib.check(L.dme_solve_set_path(path))
+            outs.append(uv.solve(st.cli_init_alphas(), 50, 0.0))
+    finally:
+        _lib.check(L.dme_solve_set_path(0))
+    for out in outs:
+        np.testing.assert_allclose(out["alpha"], ref["alpha"], rtol=RTOL_ALPHA)
+        assert out["n_iters"] == ref["n_iters"] and out["n_evals"] == ref["n_evals"]
+        np.testing.assert_allclose(out["final_loss"], oracle.total_loss(ref["alpha"], ref_st, 0.0),
+                                   rtol=RTOL_LOSS)
+        assert np.array_equal(out["alpha"], outs[0]["alpha"]) and np.array_equal(out["trace"], outs[0]["trace"])
