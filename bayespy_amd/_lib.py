@@ -27,6 +27,9 @@ SIGNATURES = {
     "dme_abi_version": (_int, []),
     "dme_last_error": (ctypes.c_char_p, []),
     "dme_device_cus": (_int, []),
+    "dme_set_cu_limit": (_int, [_int]),
+    "dme_stream_create_masked": (_int, [_vp, _int, _vp]),
+    "dme_stream_destroy": (_int, [_vp]),
     "dme_stats_workspace_bytes": (_i64, [_i64, _i64]),
     "dme_stats_staging_bytes": (_i64, [_vp, _i64, _i64, _i64, _int]),
     "dme_stats_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),

@@ -43,6 +43,17 @@ const char* dme_last_error(void);
 
 /* Number of compute units of the current device (used by callers to size workspaces). */
 int dme_device_cus(void);
+/* For callers that run the library on a CU-MASKED stream (hipExtStreamCreateWithCUMask): every launch
+ * of the calling thread is sized for `cus` compute units from now on (grids of one workgroup per CU,
+ * the solver's share of workgroups); 0 restores the device's own count.  No counterpart in the
+ * reference.  Used by benchmarks/overlap_probe.py, which runs the solver of one estimation on a few
+ * CUs beside the statistics pass of the next. */
+int dme_set_cu_limit(int cus);
+/* A stream whose kernels run only on the compute units whose bits are set in `mask` (nwords 32-bit
+ * words; bit i = CU i in the HIP runtime's numbering: hipExtStreamCreateWithCUMask), and its end.  For
+ * the same callers as dme_set_cu_limit. */
+int dme_stream_create_masked(const uint32_t* mask /*[host]*/, int nwords, void** stream /*out*/);
+int dme_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Extents for the histograms.  The reference lengthens U[k] / V as rows arrive (DE/dme.py:118, :122);
