@@ -166,15 +166,23 @@ struct StatsCfg {
 // waves: wave t of a team takes the vectors 64 * (t + TW * j) + lane, the waves' partial row totals
 // meet in LDS (a counter per team, two sets of slots), everything else is per wave as before.  The LDS image keeps its layout (vector index t + TW * j where a one-wave row has j).
 // SCAN (side-by-side rows of more than 8 lanes): row totals from a DPP prefix sum over the wave.
-template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN>
+// WIDE (side-by-side uint16 rows): 32-bit LDS counters, one column per word, so a workgroup is not
+// held to 65535 rows: narrow matrices of very many rows then leave one image per CU, not one per
+// 60000 rows (K = 8, 500 M rows: 8448 images of 100 KB to write and to sum).
+// SUB (with WIDE; K = 2 or 4 in rows that lie back to back): a 16-byte vector holds SUB whole rows,
+// a lane settles them by itself (row totals inside the lane).
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE = false, int SUB = 1>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
+    static_assert(!WIDE || (MULTI && sizeof(T) == 2 && E == 8 && J == 1), "32-bit counters: side-by-side uint16 rows");
+    static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
+    constexpr int KC = E / SUB;  // columns of a row inside a vector (SUB > 1)
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
     constexpr bool IS16 = RAW16 || PACK;    // the cells are processed as packed 16-bit counts
     constexpr int BYTES = E * (int)sizeof(T);
     constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
     constexpr int NDP = IS16 ? (E >= 2 ? E / 2 : 1) : ND;  // dwords per vector once packed
-    constexpr int PW = E >= 2 ? E / 2 : 1;          // LDS words per vector (2 columns per word)
+    constexpr int PW = WIDE ? KC : (E >= 2 ? E / 2 : 1);  // LDS words per vector (2 columns per word, or 1)
     constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK;
     constexpr int W = BLOCK / 64;
     constexpr int WR = W / TW;  // rows a workgroup has in hand per register-buffer slot
@@ -319,9 +327,20 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     auto process_buf = [&](Buf& b, long long tile, int parity) {
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
+        u32 tsub[RB][SUB];  // SUB > 1: the totals of the rows inside the lane's vector
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            if constexpr (RAW16) {
+            if constexpr (SUB > 1) {
+                constexpr int DPS = ND / SUB;  // dwords of a row
+#pragma unroll
+                for (int sr = 0; sr < SUB; ++sr) {
+                    u32 s = 0;
+#pragma unroll
+                    for (int q = 0; q < DPS; ++q) s = __builtin_amdgcn_sad_u16(b.d[rb][0][sr * DPS + q], 0u, s);
+                    tsub[rb][sr] = s;
+                }
+                tot[rb] = 0;
+            } else if constexpr (RAW16) {
                 u32 s = 0;
 #pragma unroll
                 for (int j = 0; j < J; ++j)
@@ -420,8 +439,26 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
             const long long pg = tile + goff[rb];
             if (row0 + pg * R >= row1) continue;  // wave-uniform: no such rows
             const SumT total = tot[rb];
-            double w;
-            if constexpr (MULTI) {
+            double w = 0.0;
+            double wv[SUB];  // the weight of every row inside the vector (SUB > 1)
+            if constexpr (SUB > 1) {
+                const long long rowi = row0 + pg * R + r;
+                const bool live = lane_has_row && rowi < row1;
+#pragma unroll
+                for (int sr = 0; sr < SUB; ++sr) {
+                    const u32 ts = tsub[rb][sr];
+                    if (live && ts > 0 && !DBG(8)) {
+                        if (ts < (u32)TB) {
+                            atomicAdd(&ldsV[vcopy + ts], 1u);
+                        } else {
+                            atomicMax(&sh_stat[5], (u64)ts);
+                            if ((long long)ts < tbins) atomicAdd(&a.histV[ts], 1ULL);
+                            else atomicAdd(&sh_stat[2], 1ULL);
+                        }
+                    }
+                    wv[sr] = ts < (u32)WT ? ldsW[ts] : __ddiv_rn(1.0, __dadd_rn(1.0, (double)ts));
+                }
+            } else if constexpr (MULTI) {
                 // ---- row-total histogram: the first lane of every row ----------------------
                 const long long rowi = row0 + pg * R + r;
                 if (lane_has_row && rowi < row1 && c == 0 && total > 0 && !DBG(8)) {
@@ -452,6 +489,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                 if ((u64)total < (u64)WT) w = ldsW[(u32)total];
                 else w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
             }
+            if constexpr (SUB == 1) wv[0] = w;
             // ---- cells --------------------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -503,11 +541,12 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                             for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
                                 const u32 v = h ? (dwl[q] >> 16) : (dwl[q] & 0xffffu);
                                 if (v > (u32)B) {
-                                    const long long k = (long long)opaque(chunk) * E + 2 * q + h;
+                                    const long long k = SUB > 1 ? (long long)((2 * q + h) % KC)
+                                                                : (long long)opaque(chunk) * E + 2 * q + h;
                                     atomicMax(&sh_stat[4], (u64)v);
                                     if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
                                     else atomicAdd(&sh_stat[1], 1ULL);
-                                    acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, w);
+                                    acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, wv[(2 * q + h) / KC % SUB]);
                                     dwl[q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
                                 }
                             }
@@ -526,6 +565,22 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                                 const int q = q0 + t;
                                 const u32 dw = dwl[q];
                                 const u32 lo = dw & 0xffffu;
+                                if constexpr (WIDE) {
+                                    // a word per column: columns 2q, 2q + 1 of the vector's row
+                                    const u32 hi = dw >> 16;
+                                    const u32 wb0 = laneWordByte + (u32)(((2 * q) % KC) * CW) * 4u;
+                                    const u32 wb1 = laneWordByte + (u32)(((2 * q + 1) % KC) * CW) * 4u;
+                                    if (!DBG(1)) {
+                                        atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb0)), 1u);
+                                        atomicAdd((u32*)(ldsHb + (__umul24(hi, binRowBytes) + wb1)), 1u);
+                                    }
+                                    if (!DBG(2)) {
+                                        const double ww = wv[(2 * q) / KC % SUB];
+                                        acc[j][2 * q] = mean_add(acc[j][2 * q], (double)lo, ww);
+                                        acc[j][2 * q + 1] = mean_add(acc[j][2 * q + 1], (double)hi, ww);
+                                    }
+                                    continue;
+                                }
                                 const u32 wb = laneWordByte + (u32)((j * TW * PW + q) * CW) * 4u;
                                 if (!DBG(1))
                                     atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb)), 1u);
@@ -645,11 +700,12 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                 }
             } else {
                 const int chunk = MULTI ? cc : cc + 64 * j;
-                if (chunk < C && (long long)chunk * E + e < a.K) {
+                if (chunk < C && (long long)chunk * E + e < a.K) {  // (SUB > 1: a.K = KC columns)
                     double sum = 0.0;
                     for (int w = 0; w < W; ++w)
                         for (int rr = 0; rr < R; ++rr)
-                            sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + e]);
+                            for (int sr = 0; sr < SUB; ++sr)
+                                sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + sr * KC + e]);
                     a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
                 }
             }
@@ -658,7 +714,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
 
     // ---- status ------------------------------------------------------------------------------
     // (the barriers of the accumulator exchange above order the LDS counters before these reads)
-    if (tid == 0) atomicAdd(&a.status[0], inter ? (blockIdx.x == 0 ? (u64)a.N : 0ULL) : (u64)nrows);
+    if (tid == 0) atomicAdd(&a.status[0], (u64)SUB * (inter ? (blockIdx.x == 0 ? (u64)a.N : 0ULL) : (u64)nrows));
     if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
 }
@@ -697,6 +753,8 @@ struct ReduceArgs {
     u64* status;
     long long K;
     int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi, RC;
+    int wide;  // 32-bit counters, one column per word (PW words per vector); sub > 1: the vector holds
+    int sub;   // `sub` rows of E / sub columns
     // the mean accumulators ride in the same launch: blocks from hist_blocks on sum part[g][k]
     long long hist_blocks;
     const double* part;
@@ -773,7 +831,15 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
             const bool lanes = a.multi && a.RC > 1;  // RC copies of a column's words
             const bool live = lanes ? cc < (u32)(a.RC * a.C) : true;
             const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
-            if (live && chunk < (u32)a.C) {
+            if (a.wide) {
+                if (live && chunk < (u32)a.C) {
+                    const long long k = a.sub > 1 ? (long long)p : (long long)chunk * a.E + p;
+                    const u64 cnt = slo + (shi << 16);
+                    if (lanes) atomicAdd(&a.hist[k * a.nbins + v], cnt);
+                    else a.hist[k * a.nbins + v] += cnt;
+                    maxv = maxv > (u64)v ? maxv : (u64)v;
+                }
+            } else if (live && chunk < (u32)a.C) {
                 const long long k0 = (long long)chunk * a.E + (a.E >= 2 ? 2 * p : 0);
                 if (lanes) {  // RC words per bin
                     if (slo) atomicAdd(&a.hist[k0 * a.nbins + v], slo);
@@ -798,33 +864,42 @@ constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workg
 constexpr int kMaxJ = 8;      // vectors per lane and row
 constexpr int kMaxJPack = 2;  // the same for the packed int32 kernel inside a team
 constexpr long long kRowsPerWgMax = 60000;
+constexpr long long kSubMinRows = 1 << 16;  // rows inside a vector (K = 2, 4): from this many rows on
 
 struct Plan {
     int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
+    bool wide;  // 32-bit LDS counters (side-by-side uint16 rows, very many of them)
+    int sub;    // rows inside a 16-byte vector (K = 2 or 4, rows back to back), else 1
 };
 
 // `padded`: the caller's rows are 16-byte aligned, their pitch covers K rounded up to 8 columns and
 // the columns from K on hold zeros (dme_stats_dense_*'s own staging copy, see stats_dense_staged):
 // the vectors may then run past K.
+// `sub` > 1: uint16 rows of K = 8 / sub columns that lie back to back from a 16-byte-aligned address:
+// N counts vectors of `sub` rows.
 int plan_dense(int elem_bytes, const void* X, long long N, long long K, long long ld,
-               long long nbins, long long tbins, bool padded, Plan* pl) {
+               long long nbins, long long tbins, bool padded, Plan* pl, int sub = 1) {
     int E = 16 / elem_bytes;
     const uintptr_t addr = (uintptr_t)X;
     if (addr % elem_bytes) return dme_set_error(DME_ERR_INVALID_ARG, "X is not element-aligned");
     if (padded) {
         if (addr % 16 || (ld * elem_bytes) % 16 || ld < ((K + 7) & ~7LL))
             return dme_set_error(DME_ERR_INTERNAL, "staged rows: bad pitch");
+    } else if (sub > 1) {
+        if (elem_bytes != 2 || K * sub != 8 || ld != K || addr % 16)
+            return dme_set_error(DME_ERR_INTERNAL, "rows inside a vector: bad layout");
     } else {
         while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
     }
     // int32 rows of 16-byte-aligned chunks of 8 columns, at least one chunk per lane
     const bool pack = elem_bytes == 4 && E == 4 && (padded || K % 8 == 0) && (K + 7) / 8 >= 64;
     if (pack) E = 8;
-    const long long C = (K + E - 1) / E;
+    const long long C = sub > 1 ? 1 : (K + E - 1) / E;
     Plan p{};
+    p.sub = sub;
     p.pack = pack;
     p.E = E;
     p.C = (int)C;
@@ -855,7 +930,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         p.J = (int)jtot;
         p.R = 1;
     }
-    const int PW = E >= 2 ? E / 2 : 1;
+    int PW = E >= 2 ? E / 2 : 1;
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
     // many side-by-side rows: a word per lane (see the kernel) - when there are rows enough to repay
     // the larger images that every workgroup dumps and hist_reduce_kernel sums (~20 us)
     const bool many_rows = N >= 4000000;
@@ -874,6 +951,19 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     long long avail = kLdsBudgetBytes / 4 - hoff - 4;
     // ... as many copies as leave room for all the count bins (halved until they fit)
     auto words = [&](int rc) { return !p.multi ? 64 : (rc == 1 ? (int)C : (rc == p.R ? 64 : rc * (int)C)); };
+    // 32-bit counters (see the kernel) when the rows would otherwise take several rounds of
+    // workgroups and every bin still fits in LDS; always for rows inside a vector
+    if (p.multi && elem_bytes == 2 && E == 8 && !padded &&
+        (sub > 1 || N > (long long)cus * kRowsPerWgMax)) {
+        const int PWw = E / sub;
+        int rcw = RC;
+        while (rcw > 1 && avail / ((long long)PWw * words(rcw)) - 1 < nbins - 1) rcw /= 2;
+        if (sub > 1 || avail / ((long long)PWw * words(rcw)) - 1 >= nbins - 1) {
+            p.wide = true;
+            PW = PWw;
+            RC = rcw;
+        }
+    }
     while (RC > 1 && avail / ((long long)p.J * p.TW * PW * words(RC)) - 1 < nbins - 1) RC /= 2;
     p.RC = RC;
     p.CW = words(RC);
@@ -894,12 +984,12 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const long long acc_bytes = (long long)p.block * E * 8;  // mean-accumulator exchange
     if (lds < acc_bytes) lds = acc_bytes;
     p.lds_bytes = (int)((lds + 15) & ~15LL);
-    int cus = dme_device_cus();
-    if (cus <= 0) cus = 256;
     // one workgroup per CU per round; a workgroup handles at most 65535 rows (16-bit LDS counters):
     // 60000 leaves room for the rounding of the interleaved mapping (whole loop steps)
     long long rounds = (N + (long long)cus * kRowsPerWgMax - 1) / ((long long)cus * kRowsPerWgMax);
-    if (rounds < 1) rounds = 1;
+    if (rounds < 1 || p.wide) rounds = 1;
+    if (p.wide && N / cus * sub >= (1LL << 31))
+        return dme_set_error(DME_ERR_UNSUPPORTED, "dense stats: %lld rows are more than the counters hold", N * sub);
     long long grid = (long long)cus * rounds;
     long long rpw = (N + grid - 1) / grid;
     const long long min_rows = 64LL * p.R;
@@ -917,7 +1007,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         const long long S = (long long)W * RB;
         const long long groups = (N + p.R - 1) / p.R;
         long long steps = (groups + grid * S - 1) / (grid * S);
-        if (steps * S * p.R > 65535) steps = 0;  // contiguous slabs (rows_per_wg <= 60000 each)
+        if (!p.wide && steps * S * p.R > 65535) steps = 0;  // contiguous slabs (rows_per_wg <= 60000 each)
         p.steps = (int)steps;
         if (pack) p.steps = 0;
         // rows that share cache lines with their neighbours (pitch not a multiple of 128 bytes)
@@ -928,9 +1018,10 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     return DME_OK;
 }
 
-template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1, bool SCAN = false>
+template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1, bool SCAN = false,
+          bool WIDE = false, int SUB = 1>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN>;
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
     static bool attr_set[64] = {};
     int dev = 0;
@@ -947,6 +1038,13 @@ int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
 
 template <typename T, int E>
 int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    if constexpr (sizeof(T) == 2 && E == 8) {
+        if (p.sub == 4) return launch_dense<T, E, 1, true, false, 1, false, true, 4>(a, p, s);
+        if (p.sub == 2) return launch_dense<T, E, 1, true, false, 1, false, true, 2>(a, p, s);
+        if (p.wide)
+            return p.C > 8 ? launch_dense<T, E, 1, true, false, 1, true, true>(a, p, s)
+                           : launch_dense<T, E, 1, true, false, 1, false, true>(a, p, s);
+    }
     if (p.multi)
         return p.C > 8 ? launch_dense<T, E, 1, true, false, 1, true>(a, p, s)
                        : launch_dense<T, E, 1, true>(a, p, s);
@@ -985,8 +1083,16 @@ template <typename T>
 int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
                     u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
                     long long workspace_bytes, void* stream, bool padded) {
+    // uint16 rows of 2 or 4 columns back to back: whole rows inside 16-byte vectors, the few rows
+    // that do not fill a vector afterwards on their own
+    int sub = 1;
+    if (sizeof(T) == 2 && !padded && (K == 2 || K == 4) && ld == K && ((uintptr_t)X % 16) == 0 &&
+        N >= kSubMinRows)
+        sub = (int)(8 / K);
+    const long long Nall = N;
+    if (sub > 1) N = Nall / sub;
     Plan p;
-    int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, padded, &p);
+    int rc = plan_dense((int)sizeof(T), X, N, K, ld, nbins, tbins, padded, &p, sub);
     if (rc) return rc;
     const long long init_bytes = (p.grid * K * 8 + 255) & ~255LL;
     const long long need = init_bytes + p.grid * p.part_words * 4;
@@ -995,7 +1101,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
                              workspace_bytes);
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
-    StatsArgs a{X, N, K, ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
+    StatsArgs a{X, N, K, sub > 1 ? 8LL : ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
                 p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
@@ -1037,11 +1143,11 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
         default: rc = dme_set_error(DME_ERR_INTERNAL, "bad E=%d", p.E);
     }
     if (rc) return rc;
-    const int PW = p.E >= 2 ? p.E / 2 : 1;
+    const int PW = p.wide ? p.E / p.sub : (p.E >= 2 ? p.E / 2 : 1);
     // (a team's image reads like a one-wave row's of TW * J vectors per lane)
     ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
-                  p.multi ? 1 : 0, p.RC};
+                  p.multi ? 1 : 0, p.RC, p.wide ? 1 : 0, p.sub};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
     ra.hist_blocks = (used + 255) / 256;
     ra.part = (const double*)workspace;
@@ -1049,6 +1155,9 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     hipLaunchKernelGGL(hist_reduce_kernel, dim3((unsigned)(ra.hist_blocks + (K + 63) / 64)),
                        dim3(64, RED_SLICES), 0, s, ra);
     DME_HIP_CHECK(hipGetLastError());
+    if (sub > 1 && Nall > N * sub)
+        return stats_dense_run<T>(X + N * sub * K, Nall - N * sub, K, ld, hist, nbins, histV, tbins,
+                                  init_acc, status, workspace, workspace_bytes, stream, false);
     return DME_OK;
 }
 

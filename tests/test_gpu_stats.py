@@ -741,6 +741,43 @@ def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype, big):
     np.testing.assert_allclose(ref.init_acc, exact, rtol=1e-10)
 
 
+@pytest.mark.parametrize("K,N,big,cus", [(2, 1_000_003, 0, 0), (4, 700_001, 0, 0), (2, 4_200_001, 300, 0),
+                                         (4, 300_000, 60000, 0), (2, 65_536, 0, 0), (8, 500_000, 0, 4),
+                                         (16, 400_000, 200, 4), (24, 300_001, 0, 4), (104, 300_000, 0, 4),
+                                         (8, 4_100_000, 900, 16)])
+def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big, cus):
+    """uint16 rows of 2 or 4 columns that lie back to back are read as 16-byte vectors of 4 or 2
+    whole rows (the rows that do not fill a last vector go through the ordinary kernel afterwards),
+    and side-by-side rows that would take more than one round of workgroups count in 32-bit LDS
+    words, one workgroup per CU (`cus`: the library is told it has that few CUs, so that a few
+    hundred thousand rows are already more than a round): U/V bit-exact and the mean accumulator to
+    1e-12 against the oracle's loops; `big`: a few counts far beyond the rest (copies of the bin
+    words are halved until every bin fits; at 60000 they go to global atomics)."""
+    from bayespy_amd import _lib
+    rng = np.random.default_rng(K * 1000 + N % 1000)
+    X = rng.integers(0, 7, size=(N, K), dtype=np.int32)
+    X[::5] = 0
+    X[::5, K - 1] = 33                                    # a fifth of the rows: total exactly 33
+    X[1::7] = 0                                           # empty rows
+    if big:
+        X[rng.integers(0, N, 3000), rng.integers(0, K, 3000)] = rng.integers(40, big + 1, 3000)
+    ref = oracle.append_rows(X.astype(np.uint16))
+    L = _lib.lib()
+    try:
+        if cus:
+            _lib.check(L.dme_set_cu_limit(cus))
+        st, uv, info = _build(X, "u16")
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.dme_set_cu_limit(0))
+    assert info["rows"] == N
+    _assert_uv_equal(uv, ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-10)
+    n = X.sum(axis=1, dtype=np.int64)
+    exact = (X.astype(np.longdouble) / (1 + n).astype(np.longdouble)[:, None]).sum(axis=0).astype(np.float64)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), exact, rtol=1e-12)
+
+
 @pytest.mark.parametrize("dtype", ["u16", "i32"])
 @pytest.mark.parametrize("N,K,pad", [(1, 1, 0), (300, 8, 0), (257, 1000, 0), (100, 1000, 24), (90, 13, 3),
                                      (5000, 64, 0)])
