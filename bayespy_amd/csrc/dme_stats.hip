@@ -57,6 +57,8 @@ struct StatsArgs {
     int adjacent;  // a wave's RB rows of a loop step are adjacent rows (see the kernel)
     int RC;        // side-by-side rows: copies of a column's words in a bin row (1 ... R; row slot r
                    // adds to copy r % RC)
+    int CL;        // side-by-side rows: lanes per row = ceil(C / J); lane c of a row holds the vectors
+                   // c, c + CL, ... of it
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -139,24 +141,33 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
 //   row groups: enough 16-byte loads in flight per CU (ES == 4 with E == 8 is the packed-int32 kernel:
 //     its raw buffers are twice the size).
 //   teams (TW > 1 waves share a row, see the kernel): 512 threads, one row group per buffer.
-constexpr int stats_block(int J, int E, int ES, int TW = 1) {
-    return TW > 1 ? ((J * E > 16) ? 512 : 1024)
+//   side-by-side rows of 3 / 4 vectors per lane: 1024 / 768 threads, one row group per buffer (K = 200:
+//     4.44 TB/s at 512 threads and two groups, 5.10 so; K = 600: 4.65 -> 5.09; 1024 threads spill at 4)
+//   uint16 rows of 3 / 4 / 5 vectors per lane likewise: 1024 / 768 / 768 threads (K = 1536: 4.96 -> 5.91
+//     TB/s, K = 2048: 5.26 -> 5.97, K = 2560: 4.88 -> 6.10; 6 vectors spill at 768 threads: 5.02 -> 4.09)
+constexpr int stats_block(int J, int E, int ES, int TW = 1, bool multi = false) {
+    return (multi && J == 3) ? 1024 : (multi && J == 4) ? 768
+           : (TW == 1 && ES == 2 && E == 8 && J == 3) ? 1024 : (TW == 1 && ES == 2 && E == 8 && J == 4) ? 768
+           : (TW == 1 && ES == 2 && E == 8 && J == 5) ? 768
+           : TW > 1 ? ((J * E > 16) ? 512 : 1024)
            : (J * E > 64 || (ES == 4 && J * E > 32)) ? 256 : ((J * E > 16) ? 512 : 1024);
 }
-constexpr int stats_rb(int J, int E, int ES, int TW = 1) {
-    return (TW > 1 || (ES == 4 && E == 8)) ? 1
+constexpr int stats_rb(int J, int E, int ES, int TW = 1, bool multi = false) {
+    return (multi && (J == 3 || J == 4)) ? 1
+           : (TW == 1 && ES == 2 && E == 8 && (J == 3 || J == 4)) ? 1
+           : (TW > 1 || (ES == 4 && E == 8)) ? 1
            : (J == 1)          ? DME_RB1
            : (J == 2)          ? 2
            : ((J == 3 || J == 4) && stats_block(J, E, ES) == 512) ? 2 : 1;
 }
-template <int J, int E, int ES, int TW = 1>
+template <int J, int E, int ES, int TW = 1, bool MULTI = false>
 struct StatsCfg {
-    static constexpr int BLOCK = stats_block(J, E, ES, TW);
-    static constexpr int RB = stats_rb(J, E, ES, TW);
+    static constexpr int BLOCK = stats_block(J, E, ES, TW, MULTI);
+    static constexpr int RB = stats_rb(J, E, ES, TW, MULTI);
 };
 
 // T: element type (unsigned short | int).  E: elements per vector (chunk).  J: vectors per lane
-// and row.  MULTI: a wave carries R = 64/C rows at once (then J == 1).
+// and row.  MULTI: a wave carries R rows at once, each on CL = ceil(C / J) of its lanes.
 // PACK (T = int, E = 8): int32 rows whose counts are, with rare exceptions, below 65536: a chunk
 // is loaded as two 16-byte vectors, the exceptions (and negatives) are settled one by one, and the
 // eight counts are packed into four dwords that then take the uint16 code - the int32 kernel pays
@@ -172,9 +183,10 @@ struct StatsCfg {
 // SUB (with WIDE; K = 2 or 4 in rows that lie back to back): a 16-byte vector holds SUB whole rows,
 // a lane settles them by itself (row totals inside the lane).
 template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE = false, int SUB = 1>
-__global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
+__global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
-    static_assert(!WIDE || (MULTI && sizeof(T) == 2 && E == 8 && J == 1), "32-bit counters: side-by-side uint16 rows");
+    static_assert(!WIDE || (MULTI && sizeof(T) == 2 && E == 8), "32-bit counters: side-by-side uint16 rows");
+    static_assert(SUB == 1 || J == 1, "rows inside a vector: one vector per lane");
     static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
     constexpr int KC = E / SUB;  // columns of a row inside a vector (SUB > 1)
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
@@ -183,10 +195,10 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     constexpr int ND = BYTES >= 4 ? BYTES / 4 : 1;  // dwords held per vector
     constexpr int NDP = IS16 ? (E >= 2 ? E / 2 : 1) : ND;  // dwords per vector once packed
     constexpr int PW = WIDE ? KC : (E >= 2 ? E / 2 : 1);  // LDS words per vector (2 columns per word, or 1)
-    constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK;
+    constexpr int BLOCK = StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK;
     constexpr int W = BLOCK / 64;
     constexpr int WR = W / TW;  // rows a workgroup has in hand per register-buffer slot
-    constexpr int RB = StatsCfg<J, E, (int)sizeof(T), TW>::RB;
+    constexpr int RB = StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::RB;
     typedef typename std::conditional<RAW16, u32, u64>::type SumT;
 
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
@@ -196,10 +208,11 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     const int wrow = TW > 1 ? wave / TW : wave;  // the team's (= the row's) place in the workgroup
     const int C = a.C;
     const int R = MULTI ? a.R : 1;
-    const int r = MULTI ? lane / C : 0;
-    const int c = MULTI ? lane - r * C : lane;
+    const int CL = MULTI ? a.CL : 64;  // lanes per row
+    const int r = MULTI ? lane / CL : 0;
+    const int c = MULTI ? lane - r * CL : lane;
     const bool lane_has_row = MULTI ? (r < R) : true;
-    const int CC = MULTI ? C : 64;  // column chunks a wave covers per vector index j
+    const int CC = MULTI ? CL : 64;  // column chunks a wave covers per vector index j
     const int CW = MULTI ? a.CW : 64;  // LDS words per (j, p) group of a bin row: C, or one per lane
     const int B = a.B, BRW = a.BRW, TB = a.TB;
     u32* ldsV = lds;
@@ -273,7 +286,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     // atomics, which for a handful of columns all land on a few addresses (K = 8 with counts up to
     // 500: 72 ms for 8 GB with a word per lane and 150 bins, against 2.3 ms).
     const u32 laneWordByte =
-        (u32)(MULTI ? (r % a.RC) * C + c : c) * 4u + (u32)(tw * PW * CW) * 4u;
+        (u32)(MULTI ? (r % a.RC) * CL + c : c) * 4u + (u32)(tw * PW * CW) * 4u;
     char* ldsHb = (char*)ldsH;
     const T* Xp = (const T*)a.X;
     const long long nbins = a.nbins, tbins = a.tbins;
@@ -290,7 +303,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
             const bool ok = lane_has_row && (rowi < row1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int chunk = c + 64 * (tw + TW * j);
+                const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
                 if (ok && chunk < C) {
                     load_chunk<BYTES, ND>(Xp + rowi * a.ld + (long long)chunk * E, b.d[rb][j]);
                 } else {
@@ -306,7 +319,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
     // the row's last lane and at the lane before its first (two ds_bpermute; K = 200: 2.20 -> 2.01
     // ms for 8 GB).  Shorter rows: a shuffle scan inside the row (log2(C) + 1 ds_bpermute, which
     // measured faster up to C = 8; a kernel that holds both measured slower than either).
-    const int lastLane = min(r * C + C - 1, 63), prevLane = max(r * C - 1, 0);
+    const int lastLane = min(r * CL + CL - 1, 63), prevLane = max(r * CL - 1, 0);
     auto multi_total = [&](u32 s) -> u32 {
         if constexpr (SCAN) {
             const u32 incl = dme_wave_incl_scan_u32(s);
@@ -316,7 +329,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
         } else {
             u32 incl = s;
 #pragma unroll
-            for (int dd = 1; dd < 8 && dd < C; dd <<= 1) {  // lanes of one row: c < C
+            for (int dd = 1; dd < 8 && dd < CL; dd <<= 1) {  // lanes of one row: c < CL
                 u32 up = __shfl_up(incl, dd);
                 if (c >= dd) incl += up;
             }
@@ -382,11 +395,11 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                     if constexpr (MULTI) {
                         u64 incl = s;
 #pragma unroll
-                        for (int dd = 1; dd < 64 && dd < C; dd <<= 1) {  // lanes of one row: c < C
+                        for (int dd = 1; dd < 64 && dd < CL; dd <<= 1) {  // lanes of one row: c < CL
                             u64 up = __shfl_up(incl, dd);
                             if (c >= dd) incl += up;
                         }
-                        int last = r * C + C - 1;
+                        int last = r * CL + CL - 1;
                         tot[rb] = __shfl(incl, last > 63 ? 63 : last);
                     } else {
                         tot[rb] = dme_wave_sum_u64(s);
@@ -493,7 +506,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
             // ---- cells --------------------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                const int chunk = c + 64 * (tw + TW * j);
+                const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
                 if constexpr (IS16) {
                     u32 dwl[NDP];
                     if constexpr (PACK) {
@@ -568,8 +581,8 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                                 if constexpr (WIDE) {
                                     // a word per column: columns 2q, 2q + 1 of the vector's row
                                     const u32 hi = dw >> 16;
-                                    const u32 wb0 = laneWordByte + (u32)(((2 * q) % KC) * CW) * 4u;
-                                    const u32 wb1 = laneWordByte + (u32)(((2 * q + 1) % KC) * CW) * 4u;
+                                    const u32 wb0 = laneWordByte + (u32)((j * PW + (2 * q) % KC) * CW) * 4u;
+                                    const u32 wb1 = laneWordByte + (u32)((j * PW + (2 * q + 1) % KC) * CW) * 4u;
                                     if (!DBG(1)) {
                                         atomicAdd((u32*)(ldsHb + (__umul24(lo, binRowBytes) + wb0)), 1u);
                                         atomicAdd((u32*)(ldsHb + (__umul24(hi, binRowBytes) + wb1)), 1u);
@@ -699,13 +712,13 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW>::BLOCK)) void s
                     a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
                 }
             } else {
-                const int chunk = MULTI ? cc : cc + 64 * j;
+                const int chunk = MULTI ? cc + CL * j : cc + 64 * j;
                 if (chunk < C && (long long)chunk * E + e < a.K) {  // (SUB > 1: a.K = KC columns)
                     double sum = 0.0;
                     for (int w = 0; w < W; ++w)
                         for (int rr = 0; rr < R; ++rr)
                             for (int sr = 0; sr < SUB; ++sr)
-                                sum = __dadd_rn(sum, ldsD[(w * 64 + rr * C + cc) * E + sr * KC + e]);
+                                sum = __dadd_rn(sum, ldsD[(w * 64 + rr * CL + cc) * E + sr * KC + e]);
                     a.part[(long long)blockIdx.x * a.K + (long long)chunk * E + e] = sum;
                 }
             }
@@ -753,6 +766,7 @@ struct ReduceArgs {
     u64* status;
     long long K;
     int C, R, B, BRW, TB, TBpad, VC, hoff, CW, PW, E, multi, RC;
+    int CL;    // side-by-side rows: lanes per row
     int wide;  // 32-bit counters, one column per word (PW words per vector); sub > 1: the vector holds
     int sub;   // `sub` rows of E / sub columns
     // the mean accumulators ride in the same launch: blocks from hist_blocks on sum part[g][k]
@@ -829,8 +843,8 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
             const u32 j = jp / (u32)a.PW, p = jp - j * (u32)a.PW;
             // side-by-side rows: word cc belongs to lane cc = row slot cc / C, column chunk cc % C
             const bool lanes = a.multi && a.RC > 1;  // RC copies of a column's words
-            const bool live = lanes ? cc < (u32)(a.RC * a.C) : true;
-            const u32 chunk = lanes ? cc % (u32)a.C : (a.multi ? cc : cc + 64u * j);
+            const bool live = lanes ? cc < (u32)(a.RC * a.CL) : true;
+            const u32 chunk = a.multi ? (lanes ? cc % (u32)a.CL : cc) + (u32)a.CL * j : cc + 64u * j;
             if (a.wide) {
                 if (live && chunk < (u32)a.C) {
                     const long long k = a.sub > 1 ? (long long)p : (long long)chunk * a.E + p;
@@ -867,7 +881,7 @@ constexpr long long kRowsPerWgMax = 60000;
 constexpr long long kSubMinRows = 1 << 16;  // rows inside a vector (K = 2, 4): from this many rows on
 
 struct Plan {
-    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC;
+    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC, CL;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -909,9 +923,33 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // vectors of 8 columns only: other layouts are staged first)
     const int jmax = pack ? kMaxJPack : kMaxJ;
     const long long jtot = (C + 63) / 64;
+    p.CL = 64;
     if (p.multi) {
         p.J = 1;
         p.R = (int)(64 / C);
+        p.CL = (int)C;
+    }
+    // Lanes in use: a row of C vectors on its own lanes fills C * R of 64 (K = 200: 25 * 2), and one
+    // of 65 vectors fills 65 of 128 lane slots.  uint16 rows in full vectors may instead take
+    // CL = ceil(C / J) lanes with J vectors each, R = 64 / CL rows side by side (K = 200: J = 3,
+    // 9 lanes, 7 rows: 175 of 192 slots).
+    if (elem_bytes == 2 && E == 8 && sub == 1 && C <= 4 * 64) {
+        double best = p.multi ? (double)(C * p.R) / 64.0 : (double)C / (64.0 * (double)jtot);
+        for (int j = 1; j <= 4; ++j) {
+            const long long cl = (C + j - 1) / j;
+            if (cl > 64 || (p.multi && j == 1)) continue;
+            const long long rr = 64 / cl;
+            const double u = (double)(C * rr) / (64.0 * j);
+            if (u > best * 1.08) {
+                best = u;
+                p.multi = true;
+                p.J = j;
+                p.CL = (int)cl;
+                p.R = (int)rr;
+            }
+        }
+    }
+    if (p.multi) {
     } else if (jtot > jmax && E == 8 && jtot <= (pack ? 16LL : 8LL) * jmax) {
         int TW = 2;
         while (TW * (long long)jmax < jtot) TW *= 2;
@@ -937,7 +975,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // the larger images that every workgroup dumps and hist_reduce_kernel sums (~20 us)
     const bool many_rows = N >= 4000000;
     int RC = (p.multi && p.R >= 16 && many_rows) ? p.R : 1;
-    p.block = stats_block(p.J, E, elem_bytes, p.TW);
+    p.block = stats_block(p.J, E, elem_bytes, p.TW, p.multi);
     long long TB = tbins < 2048 ? tbins : 2048;
     const long long TBpad = (TB + 3) & ~3LL;
     const long long WT = ((TB < 1024 ? TB : 1024) + 1) & ~1LL;  // even: keeps hoff a multiple of 4
@@ -950,15 +988,15 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     const long long hoff = Vw + 2 * WT;
     long long avail = kLdsBudgetBytes / 4 - hoff - 4;
     // ... as many copies as leave room for all the count bins (halved until they fit)
-    auto words = [&](int rc) { return !p.multi ? 64 : (rc == 1 ? (int)C : (rc == p.R ? 64 : rc * (int)C)); };
+    auto words = [&](int rc) { return !p.multi ? 64 : (rc == 1 ? p.CL : (rc == p.R ? 64 : rc * p.CL)); };
     // 32-bit counters (see the kernel) when the rows would otherwise take several rounds of
     // workgroups and every bin still fits in LDS; always for rows inside a vector
     if (p.multi && elem_bytes == 2 && E == 8 && !padded &&
         (sub > 1 || N > (long long)cus * kRowsPerWgMax)) {
         const int PWw = E / sub;
         int rcw = RC;
-        while (rcw > 1 && avail / ((long long)PWw * words(rcw)) - 1 < nbins - 1) rcw /= 2;
-        if (sub > 1 || avail / ((long long)PWw * words(rcw)) - 1 >= nbins - 1) {
+        while (rcw > 1 && avail / ((long long)p.J * PWw * words(rcw)) - 1 < nbins - 1) rcw /= 2;
+        if (sub > 1 || avail / ((long long)p.J * PWw * words(rcw)) - 1 >= nbins - 1) {
             p.wide = true;
             PW = PWw;
             RC = rcw;
@@ -1003,7 +1041,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // 65535 rows
     {
         const int W = p.block / 64 / p.TW;
-        const int RB = stats_rb(p.J, E, elem_bytes, p.TW);
+        const int RB = stats_rb(p.J, E, elem_bytes, p.TW, p.multi);
         const long long S = (long long)W * RB;
         const long long groups = (N + p.R - 1) / p.R;
         long long steps = (groups + grid * S - 1) / (grid * S);
@@ -1036,18 +1074,32 @@ int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
     return DME_OK;
 }
 
+// side-by-side uint16 rows in full vectors: J vectors per lane, row totals by shuffles or by a scan,
+// 16- or 32-bit counters
+template <typename T, int E, int J>
+int dispatch_multi(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    if (p.wide)
+        return p.CL > 8 ? launch_dense<T, E, J, true, false, 1, true, true>(a, p, s)
+                        : launch_dense<T, E, J, true, false, 1, false, true>(a, p, s);
+    return p.CL > 8 ? launch_dense<T, E, J, true, false, 1, true>(a, p, s)
+                    : launch_dense<T, E, J, true, false, 1, false>(a, p, s);
+}
+
 template <typename T, int E>
 int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
     if constexpr (sizeof(T) == 2 && E == 8) {
         if (p.sub == 4) return launch_dense<T, E, 1, true, false, 1, false, true, 4>(a, p, s);
         if (p.sub == 2) return launch_dense<T, E, 1, true, false, 1, false, true, 2>(a, p, s);
-        if (p.wide)
-            return p.C > 8 ? launch_dense<T, E, 1, true, false, 1, true, true>(a, p, s)
-                           : launch_dense<T, E, 1, true, false, 1, false, true>(a, p, s);
+        if (p.multi) switch (p.J) {
+            case 1: return dispatch_multi<T, E, 1>(a, p, s);
+            case 2: return dispatch_multi<T, E, 2>(a, p, s);
+            case 3: return dispatch_multi<T, E, 3>(a, p, s);
+            case 4: return dispatch_multi<T, E, 4>(a, p, s);
+        }
     }
     if (p.multi)
-        return p.C > 8 ? launch_dense<T, E, 1, true, false, 1, true>(a, p, s)
-                       : launch_dense<T, E, 1, true>(a, p, s);
+        return p.CL > 8 ? launch_dense<T, E, 1, true, false, 1, true>(a, p, s)
+                        : launch_dense<T, E, 1, true>(a, p, s);
     switch (p.J) {
         case 1: return launch_dense<T, E, 1, false>(a, p, s);
         case 2: return launch_dense<T, E, 2, false>(a, p, s);
@@ -1102,7 +1154,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, sub > 1 ? 8LL : ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC, p.CL};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if (p.TW > 1) {
@@ -1147,7 +1199,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     // (a team's image reads like a one-wave row's of TW * J vectors per lane)
     ReduceArgs ra{hist_part, p.part_words, p.grid, hist, nbins, histV, status, K,
                   p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.hoff, p.CW, PW, p.E,
-                  p.multi ? 1 : 0, p.RC, p.wide ? 1 : 0, p.sub};
+                  p.multi ? 1 : 0, p.RC, p.CL, p.wide ? 1 : 0, p.sub};
     const long long used = p.hoff + (long long)(p.B + 1) * p.BRW;
     ra.hist_blocks = (used + 255) / 256;
     ra.part = (const double*)workspace;

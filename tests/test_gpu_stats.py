@@ -744,7 +744,10 @@ def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype, big):
 @pytest.mark.parametrize("K,N,big,cus", [(2, 1_000_003, 0, 0), (4, 700_001, 0, 0), (2, 4_200_001, 300, 0),
                                          (4, 300_000, 60000, 0), (2, 65_536, 0, 0), (8, 500_000, 0, 4),
                                          (16, 400_000, 200, 4), (24, 300_001, 0, 4), (104, 300_000, 0, 4),
-                                         (8, 4_100_000, 900, 16)])
+                                         (8, 4_100_000, 900, 16),
+                                         (104, 50_000, 0, 0), (200, 100_000, 300, 0), (264, 60_000, 0, 0),
+                                         (520, 50_000, 0, 0), (600, 40_000, 300, 0), (1016, 20_000, 0, 0),
+                                         (200, 150_000, 0, 2), (48, 4_100_000, 0, 0)])
 def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big, cus):
     """uint16 rows of 2 or 4 columns that lie back to back are read as 16-byte vectors of 4 or 2
     whole rows (the rows that do not fill a last vector go through the ordinary kernel afterwards),
@@ -752,7 +755,10 @@ def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big,
     words, one workgroup per CU (`cus`: the library is told it has that few CUs, so that a few
     hundred thousand rows are already more than a round): U/V bit-exact and the mean accumulator to
     1e-12 against the oracle's loops; `big`: a few counts far beyond the rest (copies of the bin
-    words are halved until every bin fits; at 60000 they go to global atomics)."""
+    words are halved until every bin fits; at 60000 they go to global atomics).  K = 104 ... 600:
+    rows whose vectors do not fill a wave's lanes on their own lie side by side with 2 to 4 vectors
+    per lane (K = 200: 9 lanes x 3 vectors, 7 rows per wave; K = 48 at 4.1 M rows: 2 lanes x 3
+    vectors, 32 rows per wave with a bin word per row slot)."""
     from bayespy_amd import _lib
     rng = np.random.default_rng(K * 1000 + N % 1000)
     X = rng.integers(0, 7, size=(N, K), dtype=np.int32)
