@@ -141,19 +141,22 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
 //   row groups: enough 16-byte loads in flight per CU (ES == 4 with E == 8 is the packed-int32 kernel:
 //     its raw buffers are twice the size).
 //   teams (TW > 1 waves share a row, see the kernel): 512 threads, one row group per buffer.
-//   side-by-side rows of 3 / 4 vectors per lane: 1024 / 768 threads, one row group per buffer (K = 200:
-//     4.44 TB/s at 512 threads and two groups, 5.10 so; K = 600: 4.65 -> 5.09; 1024 threads spill at 4)
+//   side-by-side rows of 3 / 4 / 5 vectors per lane: 1024 / 768 / 512 threads, one row group per buffer
+//     (K = 200: 4.44 TB/s at 512 threads and two groups, 5.10 so; K = 600: 4.65 -> 5.09; 1024 threads
+//     spill at 4, 768 at 5).  The packed int32 kernel spills 40-56 bytes at 1024 threads and is still
+//     faster there than at 768 without (K = 2048: 5.51 against 4.72 TB/s).
 //   uint16 rows of 3 / 4 / 5 vectors per lane likewise: 1024 / 768 / 768 threads (K = 1536: 4.96 -> 5.91
 //     TB/s, K = 2048: 5.26 -> 5.97, K = 2560: 4.88 -> 6.10; 6 vectors spill at 768 threads: 5.02 -> 4.09)
 constexpr int stats_block(int J, int E, int ES, int TW = 1, bool multi = false) {
-    return (multi && J == 3) ? 1024 : (multi && J == 4) ? 768
+    return (multi && J == 3) ? 1024 : (multi && J == 4) ? 768 : (multi && J == 5) ? 512
            : (TW == 1 && ES == 2 && E == 8 && J == 3) ? 1024 : (TW == 1 && ES == 2 && E == 8 && J == 4) ? 768
            : (TW == 1 && ES == 2 && E == 8 && J == 5) ? 768
+           : (TW > 1 && ES == 2 && J == 3) ? 1024 : (TW > 1 && ES == 2 && J == 4 && TW <= 4) ? 768
            : TW > 1 ? ((J * E > 16) ? 512 : 1024)
            : (J * E > 64 || (ES == 4 && J * E > 32)) ? 256 : ((J * E > 16) ? 512 : 1024);
 }
 constexpr int stats_rb(int J, int E, int ES, int TW = 1, bool multi = false) {
-    return (multi && (J == 3 || J == 4)) ? 1
+    return (multi && J >= 3) ? 1
            : (TW == 1 && ES == 2 && E == 8 && (J == 3 || J == 4)) ? 1
            : (TW > 1 || (ES == 4 && E == 8)) ? 1
            : (J == 1)          ? DME_RB1
@@ -933,9 +936,9 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // of 65 vectors fills 65 of 128 lane slots.  uint16 rows in full vectors may instead take
     // CL = ceil(C / J) lanes with J vectors each, R = 64 / CL rows side by side (K = 200: J = 3,
     // 9 lanes, 7 rows: 175 of 192 slots).
-    if (elem_bytes == 2 && E == 8 && sub == 1 && C <= 4 * 64) {
+    if (elem_bytes == 2 && E == 8 && sub == 1 && C <= 5 * 64) {
         double best = p.multi ? (double)(C * p.R) / 64.0 : (double)C / (64.0 * (double)jtot);
-        for (int j = 1; j <= 4; ++j) {
+        for (int j = 1; j <= 5; ++j) {
             const long long cl = (C + j - 1) / j;
             if (cl > 64 || (p.multi && j == 1)) continue;
             const long long rr = 64 / cl;
@@ -950,6 +953,13 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         }
     }
     if (p.multi) {
+    } else if (elem_bytes == 2 && E == 8 && (jtot == 6 || jtot == 8 || (jtot >= 13 && jtot <= 16))) {
+        // two (four) waves of 3 or 4 vectors per lane at 1024 / 768 threads rather than one wave of 6
+        // or 8 (two of 8) at 512: K = 3000: 4.91 -> 5.69 TB/s, K = 4096: 5.50 -> 5.65, K = 8192: 5.20 ->
+        // 5.38; teams of 8 waves measured slower than what they would replace
+        p.TW = jtot > 8 ? 4 : 2;
+        p.J = jtot == 6 ? 3 : 4;
+        p.R = 1;
     } else if (jtot > jmax && E == 8 && jtot <= (pack ? 16LL : 8LL) * jmax) {
         int TW = 2;
         while (TW * (long long)jmax < jtot) TW *= 2;
@@ -1095,6 +1105,7 @@ int dispatch_j(const StatsArgs& a, const Plan& p, hipStream_t s) {
             case 2: return dispatch_multi<T, E, 2>(a, p, s);
             case 3: return dispatch_multi<T, E, 3>(a, p, s);
             case 4: return dispatch_multi<T, E, 4>(a, p, s);
+            case 5: return dispatch_multi<T, E, 5>(a, p, s);
         }
     }
     if (p.multi)
@@ -1122,6 +1133,8 @@ int dispatch_team(const StatsArgs& a, const Plan& p, hipStream_t s) {
         }
     } else if constexpr (sizeof(T) == 2) {
         switch (p.J) {
+            case 3: return launch_dense<T, 8, 3, false, false, TW>(a, p, s);
+            case 4: return launch_dense<T, 8, 4, false, false, TW>(a, p, s);
             case 5: return launch_dense<T, 8, 5, false, false, TW>(a, p, s);
             case 6: return launch_dense<T, 8, 6, false, false, TW>(a, p, s);
             case 7: return launch_dense<T, 8, 7, false, false, TW>(a, p, s);

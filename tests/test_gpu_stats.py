@@ -747,7 +747,8 @@ def test_per_lane_bins_bit_exact_vs_oracle(oracle, K, dtype, big):
                                          (8, 4_100_000, 900, 16),
                                          (104, 50_000, 0, 0), (200, 100_000, 300, 0), (264, 60_000, 0, 0),
                                          (520, 50_000, 0, 0), (600, 40_000, 300, 0), (1016, 20_000, 0, 0),
-                                         (200, 150_000, 0, 2), (48, 4_100_000, 0, 0)])
+                                         (200, 150_000, 0, 2), (48, 4_100_000, 0, 0), (400, 50_000, 0, 0),
+                                         (3000, 9_000, 300, 0), (4096, 7_000, 0, 0), (8000, 5_000, 0, 0)])
 def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big, cus):
     """uint16 rows of 2 or 4 columns that lie back to back are read as 16-byte vectors of 4 or 2
     whole rows (the rows that do not fill a last vector go through the ordinary kernel afterwards),
@@ -758,7 +759,8 @@ def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big,
     words are halved until every bin fits; at 60000 they go to global atomics).  K = 104 ... 600:
     rows whose vectors do not fill a wave's lanes on their own lie side by side with 2 to 4 vectors
     per lane (K = 200: 9 lanes x 3 vectors, 7 rows per wave; K = 48 at 4.1 M rows: 2 lanes x 3
-    vectors, 32 rows per wave with a bin word per row slot)."""
+    vectors, 32 rows per wave with a bin word per row slot; K = 400: 10 lanes x 5 vectors).
+    K = 3000, 4096, 8000: teams of two or four waves with 3 or 4 vectors per lane."""
     from bayespy_amd import _lib
     rng = np.random.default_rng(K * 1000 + N % 1000)
     X = rng.integers(0, 7, size=(N, K), dtype=np.int32)
