@@ -877,6 +877,232 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
     }
 }
 
+// ---- K = 2 (pairs of counts, the coin-flip shape) ------------------------------------------------
+// uint16 rows of two columns back to back, every count below nbins, nbins^2 cells small enough for
+// LDS: the pass counts the PAIRS (x0, x1) - one LDS add per row, no row total, no weight, no
+// accumulator - and everything the estimation needs is read off the pair counts afterwards:
+//   hist[0][v] = sum over x1 of pairs[v][x1],  hist[1][v] = sum over x0 of pairs[x0][v],
+//   histV[t]   = sum over x0 + x1 == t,        init_acc[k] = sum of pairs[x0][x1] * x_k / (1 + x0 + x1)
+// (the last in a fixed order: bit-reproducible).  A 16-byte vector holds four rows.  Rows with a
+// count of nbins or more (a data error that status[1] reports) are settled one by one with global
+// atomics.
+struct PairArgs {
+    const u32x4* X;
+    long long NV;          // vectors of four rows
+    int B1;                // cells per coordinate = nbins
+    int CP;                // copies of the cells (lane % CP): equal rows in one wave add to several words
+    int cstride;           // words from one copy to the next
+    long long part_words;  // words of an image, a multiple of 4
+    u32* hist_part;
+    u64* pairs;            // [B1 * B1] summed over the images
+    long long G, steps;
+    u64* hist;
+    long long nbins;
+    u64* histV;
+    long long tbins;
+    double* init_acc;
+    u64* status;
+};
+
+constexpr int PAIR_BLOCK = 1024, PAIR_RB = 4;
+constexpr int kPairLdsBytes = 150 * 1024;
+
+__device__ __noinline__ void pair_odd_row(const PairArgs& a, u32 x0, u32 x1, u64* sh_stat) {
+    const u32 total = x0 + x1;
+    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 v = k ? x1 : x0;
+        if (v == 0) continue;
+        atomicMax(&sh_stat[4], (u64)v);
+        if ((long long)v < a.nbins) atomicAdd(&a.hist[(long long)k * a.nbins + v], 1ULL);
+        else atomicAdd(&sh_stat[1], 1ULL);
+        atomicAdd(&a.init_acc[k], __dmul_rn((double)v, w));
+    }
+    atomicMax(&sh_stat[5], (u64)total);
+    if ((long long)total < a.tbins) atomicAdd(&a.histV[total], 1ULL);
+    else atomicAdd(&sh_stat[2], 1ULL);
+}
+
+__global__ __launch_bounds__(PAIR_BLOCK) void stats_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u32 lds[];
+    __shared__ u64 sh_stat[8];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)a.part_words; i += PAIR_BLOCK) lds[i] = 0;
+    if (tid < 8) sh_stat[tid] = 0;
+    __syncthreads();
+    const u32 B1 = (u32)a.B1;
+    u32* cells = lds + (u32)(tid & (a.CP - 1)) * (u32)a.cstride;
+    auto load = [&](u32x4 (&v)[PAIR_RB], long long step) {
+        const long long base = (step * gridDim.x + blockIdx.x) * (long long)(PAIR_BLOCK * PAIR_RB);
+#pragma unroll
+        for (int rb = 0; rb < PAIR_RB; ++rb) {
+            const long long g = base + rb * PAIR_BLOCK + tid;
+            v[rb] = g < a.NV ? __builtin_nontemporal_load(a.X + g) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto one = [&](u32 dw) {
+        if (dw == 0) return;  // an empty row
+        const u32 x0 = dw & 0xffffu, x1 = dw >> 16;
+        if (__builtin_expect(max(x0, x1) < B1, 1)) atomicAdd(&cells[__umul24(x0, B1) + x1], 1u);
+        else pair_odd_row(a, x0, x1, sh_stat);
+    };
+    auto process = [&](u32x4 (&v)[PAIR_RB]) {
+#pragma unroll
+        for (int rb = 0; rb < PAIR_RB; ++rb) {
+            one(v[rb].x);
+            one(v[rb].y);
+            one(v[rb].z);
+            one(v[rb].w);
+        }
+    };
+    if (a.steps > 0) {
+        u32x4 va[PAIR_RB], vb[PAIR_RB];
+        long long k = 0;
+        load(va, 0);
+        while (true) {
+            load(vb, k + 1);
+            process(va);
+            if (++k >= a.steps) break;
+            load(va, k + 1);
+            process(vb);
+            if (++k >= a.steps) break;
+        }
+    }
+    __syncthreads();
+    {
+        u32x4* dst = (u32x4*)(a.hist_part + (long long)blockIdx.x * a.part_words);
+        const u32x4* src = (const u32x4*)lds;
+        for (int i = tid; i < (int)(a.part_words >> 2); i += PAIR_BLOCK) dst[i] = src[i];
+    }
+    if (tid == 0 && blockIdx.x == 0) atomicAdd(&a.status[0], 4ULL * (u64)a.NV);
+    if (tid >= 1 && tid <= 2 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
+    if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
+}
+
+// pairs[c] = sum over the images and their copies; block (64, RED_SLICES): a thread column per cell
+__global__ __launch_bounds__(64 * RED_SLICES) void pair_sum_kernel(PairArgs a) {
+    __shared__ u64 sh[RED_SLICES][64];
+    const long long ncell = (long long)a.B1 * a.B1;
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    u64 s = 0;
+    if (c < ncell)
+        for (long long g = threadIdx.y; g < a.G; g += RED_SLICES) {
+            const u32* img = a.hist_part + g * a.part_words + c;
+            for (int cp = 0; cp < a.CP; ++cp) s += img[(long long)cp * a.cstride];
+        }
+    sh[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < ncell) {
+        u64 t = 0;
+#pragma unroll
+        for (int y = 0; y < RED_SLICES; ++y) t += sh[y][threadIdx.x];
+        a.pairs[c] = t;
+    }
+}
+
+// one workgroup: the marginals of the pair counts
+__global__ __launch_bounds__(1024) void pair_marginals_kernel(PairArgs a) {
+    __shared__ double sh0[1024], sh1[1024];
+    __shared__ u64 sh_max[2];
+    const int tid = threadIdx.x, B1 = a.B1;
+    if (tid < 2) sh_max[tid] = 0;
+    __syncthreads();
+    for (int v = 1 + tid; v < B1; v += 1024) {
+        u64 h0 = 0, h1 = 0;
+        for (int o = 0; o < B1; ++o) {
+            h0 += a.pairs[(long long)v * B1 + o];
+            h1 += a.pairs[(long long)o * B1 + v];
+        }
+        if (h0) a.hist[v] += h0;
+        if (h1) a.hist[a.nbins + v] += h1;
+        if (h0 | h1) atomicMax(&sh_max[0], (u64)v);
+    }
+    for (int t = 1 + tid; t <= 2 * (B1 - 1); t += 1024) {
+        u64 cnt = 0;
+        const int lo = t - (B1 - 1) > 0 ? t - (B1 - 1) : 0, hi = t < B1 - 1 ? t : B1 - 1;
+        for (int x0 = lo; x0 <= hi; ++x0) cnt += a.pairs[(long long)x0 * B1 + (t - x0)];
+        if (cnt) {
+            atomicMax(&sh_max[1], (u64)t);
+            if ((long long)t < a.tbins) a.histV[t] += cnt;
+            else atomicAdd(&a.status[2], cnt);
+        }
+    }
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = tid; c < B1 * B1; c += 1024) {
+        const u64 n = a.pairs[c];
+        if (n) {
+            const int x0 = c / B1, x1 = c - x0 * B1;
+            const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)(x0 + x1)));
+            s0 = __dadd_rn(s0, __dmul_rn(__dmul_rn((double)n, (double)x0), w));
+            s1 = __dadd_rn(s1, __dmul_rn(__dmul_rn((double)n, (double)x1), w));
+        }
+    }
+    sh0[tid] = s0;
+    sh1[tid] = s1;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (tid < d) {
+            sh0[tid] = __dadd_rn(sh0[tid], sh0[tid + d]);
+            sh1[tid] = __dadd_rn(sh1[tid], sh1[tid + d]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.init_acc[0] = __dadd_rn(a.init_acc[0], sh0[0]);
+        a.init_acc[1] = __dadd_rn(a.init_acc[1], sh1[0]);
+        if (sh_max[0]) atomicMax(&a.status[4], sh_max[0]);
+        if (sh_max[1]) atomicMax(&a.status[5], sh_max[1]);
+    }
+}
+
+// Returns DME_OK, an error, or -1 when the shape is not this pass's (too many bins, workspace).
+int stats_pair_run(const unsigned short* X, long long NV, u64* hist, long long nbins, u64* histV,
+                   long long tbins, double* init_acc, u64* status, void* workspace,
+                   long long workspace_bytes, hipStream_t s) {
+    if (nbins < 2 || nbins > 1024) return -1;
+    const long long ncell = nbins * nbins;
+    long long cstride = (ncell + 3) & ~3LL;
+    cstride += 1;  // odd: the copies of a cell fall into different banks
+    int CP = 64;
+    while (CP > 1 && CP * cstride * 4 > kPairLdsBytes) CP >>= 1;
+    if (CP * cstride * 4 > kPairLdsBytes) return -1;
+    int cus = dme_device_cus();
+    if (cus <= 0) cus = 256;
+    const long long per = (long long)PAIR_BLOCK * PAIR_RB;
+    long long G = (NV + per - 1) / per;
+    if (G > cus) G = cus;
+    if (G < 1) G = 1;
+    if (NV / G >= (1LL << 29)) return -1;  // 32-bit cells
+    PairArgs a{};
+    a.X = (const u32x4*)X;
+    a.NV = NV;
+    a.B1 = (int)nbins;
+    a.CP = CP;
+    a.cstride = (int)cstride;
+    a.part_words = (CP * cstride + 3) & ~3LL;
+    const long long img_bytes = (G * a.part_words * 4 + 255) & ~255LL;
+    if (!workspace || workspace_bytes < img_bytes + ncell * 8) return -1;
+    a.hist_part = (u32*)workspace;
+    a.pairs = (u64*)((char*)workspace + img_bytes);
+    a.G = G;
+    a.steps = (NV + G * per - 1) / (G * per);
+    a.hist = hist; a.nbins = nbins; a.histV = histV; a.tbins = tbins; a.init_acc = init_acc; a.status = status;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    DME_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes + 1024));
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(stats_pair_kernel, dim3((unsigned)G), dim3(PAIR_BLOCK), (size_t)(a.part_words * 4), s, a);
+    hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)((ncell + 63) / 64)), dim3(64, RED_SLICES), 0, s, a);
+    hipLaunchKernelGGL(pair_marginals_kernel, dim3(1), dim3(1024), 0, s, a);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
 constexpr int kLdsBudgetBytes = 156 * 1024;  // of the 160 KiB per CU; one workgroup per CU
 constexpr int kMaxJ = 8;      // vectors per lane and row
 constexpr int kMaxJPack = 2;  // the same for the packed int32 kernel inside a team
@@ -1154,6 +1380,17 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     if (sizeof(T) == 2 && !padded && (K == 2 || K == 4) && ld == K && ((uintptr_t)X % 16) == 0 &&
         N >= kSubMinRows)
         sub = (int)(8 / K);
+    if (sub == 4) {  // K = 2: pair counts when the bins allow
+        int rc = stats_pair_run((const unsigned short*)X, N / 4, hist, nbins, histV, tbins, init_acc,
+                                status, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc > 0) return rc;
+        if (rc == DME_OK) {
+            if (N % 4)
+                return stats_dense_run<T>(X + (N / 4) * 8, N % 4, K, ld, hist, nbins, histV, tbins,
+                                          init_acc, status, workspace, workspace_bytes, stream, false);
+            return DME_OK;
+        }
+    }
     const long long Nall = N;
     if (sub > 1) N = Nall / sub;
     Plan p;

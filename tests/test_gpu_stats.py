@@ -786,6 +786,44 @@ def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big,
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), exact, rtol=1e-12)
 
 
+@pytest.mark.parametrize("max_count,max_total", [(40, 80), (20, 30), (33, 35)])
+def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, max_total):
+    """K = 2 in uint16 rows that lie back to back counts the pairs (x0, x1) in LDS and derives
+    hist / histV / the mean accumulator from them (stats_pair_kernel); the same rows at a pitch of 4
+    take the general kernel.  Both must leave the same histograms and the same status words - also
+    when the caller's bounds are too small (counts of 33 against nbins = 21: those rows are settled
+    one by one, status[1] / status[2] report them) - and, within bounds, the oracle's U / V."""
+    dev = _dev()
+    N = 300_003                                            # three rows beyond the last full vector
+    rng = np.random.default_rng(max_count)
+    X = rng.integers(0, 9, size=(N, 2), dtype=np.int32)
+    X[::5] = (0, 33)
+    X[1::7] = 0
+    X[2::11] = (17, 0)
+    flat = torch.from_numpy(X.astype(np.uint16)).cuda()
+    wide = torch.zeros((N, 4), dtype=torch.uint16, device="cuda")
+    wide[:, :2] = flat
+    a = dev.DeviceStats(2, max_count, max_total)
+    a.add_dense(flat, max_count=max_count, max_total=max_total)
+    b = dev.DeviceStats(2, max_count, max_total)
+    b.add_dense(wide[:, :2], max_count=max_count, max_total=max_total)
+    torch.cuda.synchronize()
+    assert a.nbins == b.nbins and a.tbins == b.tbins
+    assert torch.equal(a.hist.view(2, -1)[:, 1:], b.hist.view(2, -1)[:, 1:])
+    assert torch.equal(a.histV[1:], b.histV[1:])
+    assert torch.equal(a.status, b.status)
+    np.testing.assert_allclose(a.init_acc.cpu().numpy(), b.init_acc.cpu().numpy(), rtol=1e-12)
+    if max_count >= 33 and max_total >= 35:
+        info = a.check()
+        assert info["rows"] == N
+        ref = oracle.append_rows(X.astype(np.uint16))
+        _assert_uv_equal(a.finalize(), ref)
+        np.testing.assert_allclose(a.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-10)
+    else:
+        with pytest.raises(ValueError, match="incomplete"):
+            a.check()
+
+
 @pytest.mark.parametrize("dtype", ["u16", "i32"])
 @pytest.mark.parametrize("N,K,pad", [(1, 1, 0), (300, 8, 0), (257, 1000, 0), (100, 1000, 24), (90, 13, 3),
                                      (5000, 64, 0)])
