@@ -31,7 +31,6 @@ SIGNATURES = {
     "dme_stream_create_masked": (_int, [_vp, _int, _vp]),
     "dme_stream_destroy": (_int, [_vp]),
     "dme_stats_workspace_bytes": (_i64, [_i64, _i64]),
-    "dme_stats_staging_bytes": (_i64, [_vp, _i64, _i64, _i64, _int]),
     "dme_stats_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dme_stats_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dme_bounds_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),

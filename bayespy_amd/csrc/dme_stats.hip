@@ -59,6 +59,7 @@ struct StatsArgs {
                    // adds to copy r % RC)
     int CL;        // side-by-side rows: lanes per row = ceil(C / J); lane c of a row holds the vectors
                    // c, c + CL, ... of it
+    int tail;      // K % E when the rows end inside a vector (then K >= E), else 0
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -82,15 +83,20 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// 16-byte vectors are loaded from addresses that need only be element-aligned: global memory takes
+// unaligned vector loads (one global_load_dwordx4 either way), so rows of any pitch and any K run as
+// full vectors; an aligned address costs nothing extra.
+typedef u32x4 u32x4_u __attribute__((aligned(2)));
+
 template <int BYTES, int ND>
 __device__ __forceinline__ void load_chunk(const void* p, u32 (&d)[ND]) {
     if constexpr (BYTES == 32) {
-        u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
-        u32x4 u = __builtin_nontemporal_load((const u32x4*)p + 1);
+        u32x4 v = __builtin_nontemporal_load((const u32x4_u*)p);
+        u32x4 u = __builtin_nontemporal_load((const u32x4_u*)p + 1);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         d[4] = u.x; d[5] = u.y; d[6] = u.z; d[7] = u.w;
     } else if constexpr (BYTES == 16) {
-        u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+        u32x4 v = __builtin_nontemporal_load((const u32x4_u*)p);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     } else if constexpr (BYTES == 8) {
         u32x2 v = __builtin_nontemporal_load((const u32x2*)p);
@@ -297,6 +303,15 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     struct Buf {
         u32 d[RB][J][ND];
     };
+    // what the last vector of a row keeps when the row ends inside it (a.tail elements)
+    u32 tmask[ND];
+#pragma unroll
+    for (int q = 0; q < ND; ++q) {
+        if constexpr (sizeof(T) == 2)
+            tmask[q] = (2 * q < a.tail ? 0xffffu : 0u) | (2 * q + 1 < a.tail ? 0xffff0000u : 0u);
+        else
+            tmask[q] = q < a.tail ? 0xffffffffu : 0u;
+    }
     // issue the loads of this wave's RB row groups of the tile at row group `tile` (nothing is
     // waited for here; a tile beyond the last one holds no rows below row1)
     auto load_buf = [&](Buf& b, long long tile) {
@@ -308,7 +323,32 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
             for (int j = 0; j < J; ++j) {
                 const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
                 if (ok && chunk < C) {
-                    load_chunk<BYTES, ND>(Xp + rowi * a.ld + (long long)chunk * E, b.d[rb][j]);
+                    if (BYTES >= 16 && a.tail && __builtin_expect(chunk == C - 1 && rowi == a.N - 1, 0)) {
+                        // The matrix ends inside this vector (the last vector of the last row; the
+                        // last vectors of the other rows run on into the next row and are masked in
+                        // process_buf): load the E elements that END with the row (K >= E: nothing
+                        // beyond the matrix is touched) and move the a.tail elements that belong to
+                        // this vector to its front.
+                        u32 w[ND];
+                        load_chunk<BYTES, ND>(Xp + rowi * a.ld + a.K - E, w);
+                        const int sh = E - a.tail;  // elements to drop from the front: 1 .. E - 1
+                        const int ds = sizeof(T) == 2 ? sh >> 1 : sh;  // whole dwords
+                        u32 t[ND + 1];
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) {
+                            t[q] = 0;
+#pragma unroll
+                            for (int sft = 0; sft < ND; ++sft)
+                                if (q + sft < ND && ds == sft) t[q] = w[q + sft];
+                        }
+                        t[ND] = 0;
+                        const bool half = sizeof(T) == 2 && (sh & 1);
+#pragma unroll
+                        for (int q = 0; q < ND; ++q)
+                            b.d[rb][j][q] = half ? (t[q] >> 16) | (t[q + 1] << 16) : t[q];
+                    } else {
+                        load_chunk<BYTES, ND>(Xp + rowi * a.ld + (long long)chunk * E, b.d[rb][j]);
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < ND; ++q) b.d[rb][j][q] = 0;
@@ -341,6 +381,19 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     };
 
     auto process_buf = [&](Buf& b, long long tile, int parity) {
+        // rows that end inside a vector: clear what the last vector of a row holds beyond the row
+        if (BYTES >= 16 && a.tail) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
+                if (chunk == C - 1) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int q = 0; q < ND; ++q) b.d[rb][j][q] &= tmask[q];
+                }
+            }
+        }
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
         u32 tsub[RB][SUB];  // SUB > 1: the totals of the rows inside the lane's vector
@@ -1110,7 +1163,7 @@ constexpr long long kRowsPerWgMax = 60000;
 constexpr long long kSubMinRows = 1 << 16;  // rows inside a vector (K = 2, 4): from this many rows on
 
 struct Plan {
-    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC, CL;
+    int E, J, TW, C, R, B, BRW, TB, TBpad, WT, hoff, block, lds_bytes, rows_per_wg, steps, adjacent, VC, CW, Vw, RC, CL, tail;
     long long grid, part_words;
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
@@ -1119,8 +1172,7 @@ struct Plan {
 };
 
 // `padded`: the caller's rows are 16-byte aligned, their pitch covers K rounded up to 8 columns and
-// the columns from K on hold zeros (dme_stats_dense_*'s own staging copy, see stats_dense_staged):
-// the vectors may then run past K.
+// the columns from K on hold zeros: the vectors may then run past K (no caller at present).
 // `sub` > 1: uint16 rows of K = 8 / sub columns that lie back to back from a 16-byte-aligned address:
 // N counts vectors of `sub` rows.
 int plan_dense(int elem_bytes, const void* X, long long N, long long K, long long ld,
@@ -1130,18 +1182,21 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     if (addr % elem_bytes) return dme_set_error(DME_ERR_INVALID_ARG, "X is not element-aligned");
     if (padded) {
         if (addr % 16 || (ld * elem_bytes) % 16 || ld < ((K + 7) & ~7LL))
-            return dme_set_error(DME_ERR_INTERNAL, "staged rows: bad pitch");
+            return dme_set_error(DME_ERR_INTERNAL, "padded rows: bad pitch");
     } else if (sub > 1) {
         if (elem_bytes != 2 || K * sub != 8 || ld != K || addr % 16)
             return dme_set_error(DME_ERR_INTERNAL, "rows inside a vector: bad layout");
-    } else {
+    } else if (K < E) {
+        // rows shorter than a vector: narrower loads
         while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
     }
-    // int32 rows of 16-byte-aligned chunks of 8 columns, at least one chunk per lane
-    const bool pack = elem_bytes == 4 && E == 4 && (padded || K % 8 == 0) && (K + 7) / 8 >= 64;
+    // (otherwise full vectors whatever the pitch and the alignment: see load_chunk and `tail`)
+    // int32 rows in chunks of 8 columns, at least one chunk per lane
+    const bool pack = elem_bytes == 4 && E == 4 && (K + 7) / 8 >= 64;
     if (pack) E = 8;
     const long long C = sub > 1 ? 1 : (K + E - 1) / E;
     Plan p{};
+    p.tail = (!padded && sub == 1 && K >= E) ? (int)(K % E) : 0;
     p.sub = sub;
     p.pack = pack;
     p.E = E;
@@ -1149,7 +1204,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     p.TW = 1;
     p.multi = C < 64;
     // vectors per lane that one wave takes; longer rows go to teams of 2, 4 or 8 waves (full
-    // vectors of 8 columns only: other layouts are staged first)
+    // vectors of 8 columns only)
     const int jmax = pack ? kMaxJPack : kMaxJ;
     const long long jtot = (C + 63) / 64;
     p.CL = 64;
@@ -1404,7 +1459,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, sub > 1 ? 8LL : ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC, p.CL};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC, p.CL, p.tail};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if (p.TW > 1) {
@@ -1472,54 +1527,6 @@ long long base_workspace_bytes(long long N, long long K) {
     return ((long long)cus * rounds * (K * 8 + kLdsBudgetBytes + 64) + 1024 + 255) & ~255LL;
 }
 
-constexpr long long kStageBytes = 256LL << 20;  // rows staged per round, at most
-constexpr long long kStageMinRows = 4096;
-
-// Layouts the vector loads cannot take as they lie (rows that are not 16-byte aligned, K not a
-// multiple of the vector) with more columns than the narrow-vector kernels hold: the rows are copied,
-// a block at a time, into a 16-byte-aligned staging area behind the workspace whose pitch is K
-// rounded up to 8 columns (the pad columns zeroed), and the block runs as full vectors.  One extra
-// read and write of X; hipMemcpy2DAsync does the copy, nothing is allocated.
-template <typename T>
-int stats_dense_staged(const T* X, long long N, long long K, long long ld, u64* hist,
-                       long long nbins, u64* histV, long long tbins, double* init_acc, u64* status,
-                       void* workspace, long long workspace_bytes, void* stream) {
-    const long long Kp = (K + 7) & ~7LL;
-    const long long row_bytes = Kp * (long long)sizeof(T);
-    const long long base = base_workspace_bytes(N, Kp);
-    long long rows = (workspace_bytes - base) / row_bytes;
-    if (rows > N) rows = N;
-    const long long want = N < kStageMinRows ? N : kStageMinRows;
-    if (!workspace || workspace_bytes < base || rows < want)
-        return dme_set_error(DME_ERR_WORKSPACE,
-                             "stats workspace: this layout (K=%lld, pitch %lld) is staged: need "
-                             "dme_stats_workspace_bytes + dme_stats_staging_bytes, got %lld bytes",
-                             K, ld, workspace_bytes);
-    DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
-    char* stage = (char*)workspace + base;
-    hipStream_t s = (hipStream_t)stream;
-    for (long long r0 = 0; r0 < N; r0 += rows) {
-        const long long nb = N - r0 < rows ? N - r0 : rows;
-        if (Kp > K)
-            DME_HIP_CHECK(hipMemset2DAsync(stage + K * sizeof(T), (size_t)row_bytes, 0,
-                                           (size_t)((Kp - K) * sizeof(T)), (size_t)nb, s));
-        DME_HIP_CHECK(hipMemcpy2DAsync(stage, (size_t)row_bytes, X + r0 * ld, (size_t)(ld * sizeof(T)),
-                                       (size_t)(K * sizeof(T)), (size_t)nb, hipMemcpyDeviceToDevice, s));
-        int rc = stats_dense_run<T>((const T*)stage, nb, K, Kp, hist, nbins, histV, tbins, init_acc,
-                                    status, workspace, base, stream, true);
-        if (rc) return rc;
-    }
-    return DME_OK;
-}
-
-// whether the rows have to be staged: the plan as they lie is refused, the staged one is not
-bool needs_staging(int elem_bytes, const void* X, long long N, long long K, long long ld) {
-    Plan p;
-    if (plan_dense(elem_bytes, X, N, K, ld, 2, 2, false, &p) == DME_OK) return false;
-    const long long jtot = (((K + 7) / 8) + 63) / 64;
-    return jtot <= (elem_bytes == 4 ? 16LL * kMaxJPack : 8LL * kMaxJ);
-}
-
 template <typename T>
 int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
                 u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
@@ -1530,9 +1537,6 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(K * nbins < (1LL << 40), "hist too large");
     if (N == 0) return DME_OK;
     DME_REQUIRE(X != nullptr, "X is null");
-    if (needs_staging((int)sizeof(T), X, N, K, ld))
-        return stats_dense_staged<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status,
-                                     workspace, workspace_bytes, stream);
     return stats_dense_run<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status, workspace,
                               workspace_bytes, stream, false);
 }
@@ -1541,17 +1545,6 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
 
 extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
     return (int64_t)base_workspace_bytes(N, (K + 7) & ~7LL);
-}
-
-extern "C" int64_t dme_stats_staging_bytes(const void* X, int64_t N, int64_t K, int64_t ld,
-                                           int elem_bytes) {
-    if ((elem_bytes != 2 && elem_bytes != 4) || N <= 0 || K < 1 || ld < K) return 0;
-    if (!needs_staging(elem_bytes, X, N, K, ld)) return 0;
-    const long long row_bytes = ((K + 7) & ~7LL) * elem_bytes;
-    long long rows = kStageBytes / row_bytes;
-    if (rows < kStageMinRows) rows = kStageMinRows;
-    if (rows > N) rows = N;
-    return (int64_t)(rows * row_bytes);
 }
 
 extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,

@@ -302,9 +302,6 @@ class DeviceStats:
 
     def _workspace(self, N, X=None):
         need = _lib.lib().dme_stats_workspace_bytes(int(N), self.K) + 256
-        if X is not None:  # layouts that the library stages first (odd pitch with many columns)
-            need += _lib.lib().dme_stats_staging_bytes(X.data_ptr(), X.shape[0], self.K,
-                                                       X.stride(0), X.element_size())
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)

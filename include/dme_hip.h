@@ -90,22 +90,18 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  * The caller must check status[1..3] == 0 and status[6] == 0 (they are data errors, reported after the fact so
  * that the pass stays asynchronous).
  *
- * X is row-major, `ld` elements between rows (ld >= K).  Rows whose start and pitch are 16-byte
- * aligned and whose K is a multiple of 8 are read as they lie, in 16-byte vectors: uint16 up to
+ * X is row-major, `ld` elements between rows (ld >= K).  Rows of 8 uint16 / 4 int32 columns or more
+ * are read in 16-byte vectors whatever their pitch, alignment and K (global memory takes unaligned
+ * vector loads; a row that ends inside a vector has its last vector loaded shifted): uint16 up to
  * K = 32 768, int32 up to K = 16 384 (from 512 columns on int32 rows run in chunks of 8 columns like
- * uint16 rows; counts of 65536 and more are legal and settled one by one).  Rows of more than 4096
- * uint16 / 2048 int32 columns are split over teams of 2, 4 or 8 waves.  Other layouts (odd pitch,
- * K not a multiple of the vector) are read in narrower vectors of E elements while
- * ceil(K / E / 64) <= 8, and otherwise STAGED: copied, a block of rows at a time, into a padded
- * 16-byte-aligned area behind the workspace (one extra read and write of X).  Beyond the column
- * limits: DME_ERR_UNSUPPORTED (use the CSR entry).
- * workspace [dev], 256-byte aligned: dme_stats_workspace_bytes(N, K) bytes, plus
- * dme_stats_staging_bytes(X, N, K, ld, sizeof(elem)) bytes (0 unless this layout is staged; any
- * amount that holds 4096 rows of K rounded up to 8 columns will do, more means fewer rounds).
+ * uint16 rows; counts of 65536 and more are legal and settled one by one).  Rows that do not fill a
+ * wave lie side by side in it, rows of more than 8 vectors per lane are split over teams of 2, 4 or
+ * 8 waves.  Narrow uint16 rows that lie back to back from a 16-byte-aligned address: K = 4 as two
+ * rows per vector, K = 2 as pair counts (see dme_stats.hip).  Beyond the column limits:
+ * DME_ERR_UNSUPPORTED (use the CSR entry).
+ * workspace [dev], 256-byte aligned: dme_stats_workspace_bytes(N, K) bytes.
  * ------------------------------------------------------------------------------------------- */
 int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);
-int64_t dme_stats_staging_bytes(const void* X /*[dev], only its alignment is looked at*/, int64_t N,
-                                int64_t K, int64_t ld, int elem_bytes);
 
 int dme_stats_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
                         uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,

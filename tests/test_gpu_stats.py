@@ -240,7 +240,8 @@ def test_large_synthetic_properties(oracle):
 
 WIDE = [
     # (N, K, ld, dtype): rows split over teams of 2 / 4 / 8 waves, every J the teams are built for,
-    # the team edges, staged layouts (odd pitch or K, then the same kernels on the padded copy)
+    # the team edges, odd pitches and K that is no multiple of the vector (unaligned vector loads, the
+    # last vector of a row loaded shifted)
     (700, 4104, 4104, "u16"), (300, 5120, 5120, "u16"), (300, 6000, 6000, "u16"),
     (300, 7168, 7176, "u16"), (260, 8192, 8192, "u16"), (150, 8200, 8200, "u16"),
     (150, 12000, 12000, "u16"), (120, 16384, 16384, "u16"), (90, 16392, 16392, "u16"),
@@ -255,9 +256,9 @@ WIDE = [
 
 
 @pytest.mark.parametrize("N,K,ld,dtype", WIDE)
-def test_wide_and_staged_rows_bit_exact_vs_oracle(oracle, N, K, ld, dtype):
-    """Rows wider than one wave takes (teams of waves share a row) and layouts that the library
-    stages first: same statistics as the oracle, through the dense C entry alone."""
+def test_wide_and_odd_rows_bit_exact_vs_oracle(oracle, N, K, ld, dtype):
+    """Rows wider than one wave takes (teams of waves share a row), also at odd pitches and widths:
+    same statistics as the oracle, through the dense C entry alone."""
     dev = _dev()
     rng = np.random.default_rng(K * 7 + N)
     npdt = np.uint16 if dtype == "u16" else np.int32
@@ -283,7 +284,7 @@ def test_wide_and_staged_rows_bit_exact_vs_oracle(oracle, N, K, ld, dtype):
 def test_dense_layouts_fuzz_vs_oracle(oracle, seed):
     """Random shapes through the dense entry: any K up to the team range, any pitch, any element
     offset of the base pointer, both element types - whichever kernel the plan picks (vectors of 1
-    to 8 elements, 1 to 8 of them per lane, side-by-side rows, packed int32, teams, staging), the
+    to 8 elements, 1 to 8 of them per lane, side-by-side rows, packed int32, teams, odd row ends), the
     statistics are the oracle's."""
     dev = _dev()
     rng = np.random.default_rng(1000 + seed)
@@ -314,8 +315,10 @@ def test_dense_layouts_fuzz_vs_oracle(oracle, seed):
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
 
 
-def test_staged_rows_in_several_rounds(oracle):
-    """A staging area that holds a part of the rows only: the rounds add up."""
+def test_rows_that_end_inside_a_vector_at_size(oracle):
+    """K = 1001 uint16 at pitch 1001: no row but the first is even 4-byte aligned and every row ends
+    one element into its last vector (loaded shifted, from inside the row); the workspace is
+    dme_stats_workspace_bytes alone."""
     from bayespy_amd import _lib
     dev = _dev()
     rng = np.random.default_rng(31)
@@ -324,8 +327,7 @@ def test_staged_rows_in_several_rounds(oracle):
     Xd = torch.from_numpy(X).cuda()
     st = dev.DeviceStats(K, 8, int(X.sum(axis=1).max()))
     L = _lib.lib()
-    assert L.dme_stats_staging_bytes(Xd.data_ptr(), N, K, K, 2) == N * 1008 * 2
-    need = L.dme_stats_workspace_bytes(N, K) + 4096 * 1008 * 2 + 256  # 4096 of the 9000 rows
+    need = L.dme_stats_workspace_bytes(N, K) + 256
     ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
     off = (-ws.data_ptr()) % 256
     _lib.check(L.dme_stats_dense_u16(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins,
@@ -336,13 +338,6 @@ def test_staged_rows_in_several_rounds(oracle):
     ref = oracle.append_rows(X)
     _assert_uv_equal(st.finalize(), ref)
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
-    # without the staging bytes the call is refused, and says what it needs
-    with pytest.raises(Exception, match="staged"):
-        _lib.check(L.dme_stats_dense_u16(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins,
-                                         st.histV.data_ptr(), st.tbins, st.init_acc.data_ptr(),
-                                         st.status.data_ptr(), ws.data_ptr() + off,
-                                         L.dme_stats_workspace_bytes(N, K),
-                                         torch.cuda.current_stream().cuda_stream))
 
 
 @pytest.mark.parametrize("K,dtype", [(40000, "u16"), (20000, "i32"), (50000, "i32")])
@@ -675,11 +670,11 @@ def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
                                        (32768, 40_000, "u16"), (2048, 300_000, "i32"), (4096, 200_000, "i32"),
                                        (8192, 80_000, "i32"), (16384, 40_000, "i32"), (6001, 90_000, "u16")])
 def test_long_rows_at_size_against_torch_reductions(K, N, dtype):
-    """Rows shared by teams of waves (and K = 3000: six vectors per lane; K = 6001: staged, then a
+    """Rows shared by teams of waves (and K = 3000: six vectors per lane; K = 6001: odd row ends in a
     team) over enough rows that every workgroup runs many loop steps of the interleaved / slab
     mappings: row count, column sums, grand total and the row-total histogram against torch
     reductions (size-independent properties; the small shapes are compared with the oracle cell by
-    cell in test_wide_and_staged_rows_bit_exact_vs_oracle)."""
+    cell in test_wide_and_odd_rows_bit_exact_vs_oracle)."""
     dev = _dev()
     rng = np.random.default_rng(K)
     alpha = 0.002 + rng.gamma(2.0, 0.01, size=K)
