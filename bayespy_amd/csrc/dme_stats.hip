@@ -191,11 +191,14 @@ struct StatsCfg {
 // 60000 rows (K = 8, 500 M rows: 8448 images of 100 KB to write and to sum).
 // SUB (with WIDE; K = 2 or 4 in rows that lie back to back): a 16-byte vector holds SUB whole rows,
 // a lane settles them by itself (row totals inside the lane).
-template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE = false, int SUB = 1>
+// TAIL: the rows end inside their last vector (a.tail elements of it belong to the row).
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE = false, int SUB = 1,
+          bool TAIL = false>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
     static_assert(!WIDE || (MULTI && sizeof(T) == 2 && E == 8), "32-bit counters: side-by-side uint16 rows");
     static_assert(SUB == 1 || J == 1, "rows inside a vector: one vector per lane");
+    static_assert(!TAIL || (E * sizeof(T) >= 16 && SUB == 1), "row ends inside full vectors only");
     static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
     constexpr int KC = E / SUB;  // columns of a row inside a vector (SUB > 1)
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
@@ -303,15 +306,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     struct Buf {
         u32 d[RB][J][ND];
     };
-    // what the last vector of a row keeps when the row ends inside it (a.tail elements)
-    u32 tmask[ND];
-#pragma unroll
-    for (int q = 0; q < ND; ++q) {
-        if constexpr (sizeof(T) == 2)
-            tmask[q] = (2 * q < a.tail ? 0xffffu : 0u) | (2 * q + 1 < a.tail ? 0xffff0000u : 0u);
-        else
-            tmask[q] = q < a.tail ? 0xffffffffu : 0u;
-    }
+
     // issue the loads of this wave's RB row groups of the tile at row group `tile` (nothing is
     // waited for here; a tile beyond the last one holds no rows below row1)
     auto load_buf = [&](Buf& b, long long tile) {
@@ -323,7 +318,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
             for (int j = 0; j < J; ++j) {
                 const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
                 if (ok && chunk < C) {
-                    if (BYTES >= 16 && a.tail && __builtin_expect(chunk == C - 1 && rowi == a.N - 1, 0)) {
+                    if (TAIL && __builtin_expect(chunk == C - 1 && rowi == a.N - 1, 0)) {
                         // The matrix ends inside this vector (the last vector of the last row; the
                         // last vectors of the other rows run on into the next row and are masked in
                         // process_buf): load the E elements that END with the row (K >= E: nothing
@@ -382,7 +377,16 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
 
     auto process_buf = [&](Buf& b, long long tile, int parity) {
         // rows that end inside a vector: clear what the last vector of a row holds beyond the row
-        if (BYTES >= 16 && a.tail) {
+        if constexpr (TAIL) {
+            // what the last vector of a row keeps (a.tail elements)
+            u32 tmask[ND];
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                if constexpr (sizeof(T) == 2)
+                    tmask[q] = (2 * q < a.tail ? 0xffffu : 0u) | (2 * q + 1 < a.tail ? 0xffff0000u : 0u);
+                else
+                    tmask[q] = q < a.tail ? 0xffffffffu : 0u;
+            }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int chunk = MULTI ? c + CL * j : c + 64 * (tw + TW * j);
@@ -1347,10 +1351,21 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     return DME_OK;
 }
 
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE, int SUB, bool TAIL>
+int launch_dense_t(const StatsArgs& a, const Plan& p, hipStream_t s);
+
 template <typename T, int E, int J, bool MULTI, bool PACK = false, int TW = 1, bool SCAN = false,
           bool WIDE = false, int SUB = 1>
 int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB>;
+    if constexpr (E * sizeof(T) >= 16 && SUB == 1) {
+        if (p.tail) return launch_dense_t<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, true>(a, p, s);
+    }
+    return launch_dense_t<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, false>(a, p, s);
+}
+
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE, int SUB, bool TAIL>
+int launch_dense_t(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
     static bool attr_set[64] = {};
     int dev = 0;

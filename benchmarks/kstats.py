@@ -13,4 +13,4 @@ q = (f"select s.kernel_name,count(*),avg(d.end-d.start)/1e3,min(d.end-d.start)/1
      f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 3 desc")
 for r in cur.execute(q):
     if flt in r[0]:
-        print("%-64s n=%5d avg %9.1f us  min %9.1f  max %9.1f" % (r[0][:64], r[1], r[2], r[3], r[4]))
+        print("%-88s n=%5d avg %9.1f us  min %9.1f  max %9.1f" % (r[0][:88], r[1], r[2], r[3], r[4]))
