@@ -1558,6 +1558,12 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
 
 }  // namespace
 
+// The file is compiled twice (Makefile), once per element type, so that the two halves of the kernel
+// instantiations build side by side: DME_STATS_PART 0 = uint16 (+ the shared entry), 1 = int32.
+#ifndef DME_STATS_PART
+#define DME_STATS_PART -1
+#endif
+#if DME_STATS_PART != 1
 extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
     return (int64_t)base_workspace_bytes(N, (K + 7) & ~7LL);
 }
@@ -1570,6 +1576,8 @@ extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int6
                                        (u64*)status, workspace, workspace_bytes, stream);
 }
 
+#endif
+#if DME_STATS_PART != 0
 extern "C" int dme_stats_dense_i32(const int32_t* X, int64_t N, int64_t K, int64_t ld,
                                    uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
                                    double* init_acc, uint64_t* status, void* workspace,
@@ -1577,3 +1585,4 @@ extern "C" int dme_stats_dense_i32(const int32_t* X, int64_t N, int64_t K, int64
     return stats_dense<int>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
                             (u64*)status, workspace, workspace_bytes, stream);
 }
+#endif
