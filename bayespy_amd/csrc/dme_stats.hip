@@ -150,11 +150,13 @@ __device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) {
 //   side-by-side rows of 3 / 4 / 5 vectors per lane: 1024 / 768 / 512 threads, one row group per buffer
 //     (K = 200: 4.44 TB/s at 512 threads and two groups, 5.10 so; K = 600: 4.65 -> 5.09; 1024 threads
 //     spill at 4, 768 at 5).  The packed int32 kernel spills 40-56 bytes at 1024 threads and is still
-//     faster there than at 768 without (K = 2048: 5.51 against 4.72 TB/s).
+//     faster there than at 768 without (K = 2048: 5.51 against 4.72 TB/s; 512 threads with two row
+//     groups per buffer: K = 1000 4.05 against 5.55).
 //   uint16 rows of 3 / 4 / 5 vectors per lane likewise: 1024 / 768 / 768 threads (K = 1536: 4.96 -> 5.91
 //     TB/s, K = 2048: 5.26 -> 5.97, K = 2560: 4.88 -> 6.10; 6 vectors spill at 768 threads: 5.02 -> 4.09)
 constexpr int stats_block(int J, int E, int ES, int TW = 1, bool multi = false) {
     return (multi && J == 3) ? 1024 : (multi && J == 4) ? 768 : (multi && J == 5) ? 512
+           : (multi && ES == 4 && E == 8 && J == 2) ? 768
            : (TW == 1 && ES == 2 && E == 8 && J == 3) ? 1024 : (TW == 1 && ES == 2 && E == 8 && J == 4) ? 768
            : (TW == 1 && ES == 2 && E == 8 && J == 5) ? 768
            : (TW > 1 && ES == 2 && J == 3) ? 1024 : (TW > 1 && ES == 2 && J == 4 && TW <= 4) ? 768
@@ -164,6 +166,7 @@ constexpr int stats_block(int J, int E, int ES, int TW = 1, bool multi = false) 
 constexpr int stats_rb(int J, int E, int ES, int TW = 1, bool multi = false) {
     return (multi && J >= 3) ? 1
            : (TW == 1 && ES == 2 && E == 8 && (J == 3 || J == 4)) ? 1
+           : (TW == 1 && ES == 4 && E == 8 && J == 1) ? 2
            : (TW > 1 || (ES == 4 && E == 8)) ? 1
            : (J == 1)          ? DME_RB1
            : (J == 2)          ? 2
@@ -1195,8 +1198,8 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         while (E > 1 && (K % E || ld % E || (addr % ((uintptr_t)E * elem_bytes)))) E >>= 1;
     }
     // (otherwise full vectors whatever the pitch and the alignment: see load_chunk and `tail`)
-    // int32 rows in chunks of 8 columns, at least one chunk per lane
-    const bool pack = elem_bytes == 4 && E == 4 && (K + 7) / 8 >= 64;
+    // int32 rows in chunks of 8 columns (rows of fewer than 64 chunks side by side, like uint16 rows)
+    const bool pack = elem_bytes == 4 && E == 4 && K >= 8;
     if (pack) E = 8;
     const long long C = sub > 1 ? 1 : (K + E - 1) / E;
     Plan p{};
@@ -1221,14 +1224,16 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // of 65 vectors fills 65 of 128 lane slots.  uint16 rows in full vectors may instead take
     // CL = ceil(C / J) lanes with J vectors each, R = 64 / CL rows side by side (K = 200: J = 3,
     // 9 lanes, 7 rows: 175 of 192 slots).
-    if (elem_bytes == 2 && E == 8 && sub == 1 && C <= 5 * 64) {
+    if (E == 8 && sub == 1 && C <= (pack ? 2 : 5) * 64) {
         double best = p.multi ? (double)(C * p.R) / 64.0 : (double)C / (64.0 * (double)jtot);
-        for (int j = 1; j <= 5; ++j) {
+        for (int j = 1; j <= (pack ? 2 : 5); ++j) {
             const long long cl = (C + j - 1) / j;
             if (cl > 64 || (p.multi && j == 1)) continue;
             const long long rr = 64 / cl;
             const double u = (double)(C * rr) / (64.0 * j);
-            if (u > best * 1.08) {
+            // (the packed int32 kernel of two vectors per lane runs 768 threads: K = 100 measured 4.45
+            // TB/s with one vector per lane on 52 lanes against 3.67 with two on 63)
+            if (u > best * (pack ? 1.3 : 1.08)) {
                 best = u;
                 p.multi = true;
                 p.J = j;
@@ -1496,7 +1501,20 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
             }
         }
     } else if constexpr (sizeof(T) == 4) {
-        if (p.pack) {
+        if (p.pack && p.multi) {
+            const bool scan = p.CL > 8;
+            switch (p.J) {
+                case 1:
+                    rc = scan ? launch_dense<T, 8, 1, true, true, 1, true>(a, p, s)
+                              : launch_dense<T, 8, 1, true, true, 1, false>(a, p, s);
+                    break;
+                case 2:
+                    rc = scan ? launch_dense<T, 8, 2, true, true, 1, true>(a, p, s)
+                              : launch_dense<T, 8, 2, true, true, 1, false>(a, p, s);
+                    break;
+                default: rc = dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
+            }
+        } else if (p.pack) {
             switch (p.J) {
                 case 1: rc = launch_dense<T, 8, 1, false, true>(a, p, s); break;
                 case 2: rc = launch_dense<T, 8, 2, false, true>(a, p, s); break;
