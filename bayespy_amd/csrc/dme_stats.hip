@@ -199,7 +199,7 @@ template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bo
           bool TAIL = false>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
-    static_assert(!WIDE || (MULTI && sizeof(T) == 2 && E == 8), "32-bit counters: side-by-side uint16 rows");
+    static_assert(!WIDE || (MULTI && (sizeof(T) == 2 || PACK) && E == 8), "32-bit counters: side-by-side rows of 16-bit cells");
     static_assert(SUB == 1 || J == 1, "rows inside a vector: one vector per lane");
     static_assert(!TAIL || (E * sizeof(T) >= 16 && SUB == 1), "row ends inside full vectors only");
     static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
@@ -1291,7 +1291,7 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     auto words = [&](int rc) { return !p.multi ? 64 : (rc == 1 ? p.CL : (rc == p.R ? 64 : rc * p.CL)); };
     // 32-bit counters (see the kernel) when the rows would otherwise take several rounds of
     // workgroups and every bin still fits in LDS; always for rows inside a vector
-    if (p.multi && elem_bytes == 2 && E == 8 && !padded &&
+    if (p.multi && (elem_bytes == 2 || pack) && E == 8 && !padded &&
         (sub > 1 || N > (long long)cus * kRowsPerWgMax)) {
         const int PWw = E / sub;
         int rcw = RC;
@@ -1503,14 +1503,22 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     } else if constexpr (sizeof(T) == 4) {
         if (p.pack && p.multi) {
             const bool scan = p.CL > 8;
-            switch (p.J) {
-                case 1:
+            switch (p.J * 2 + (p.wide ? 1 : 0)) {
+                case 2:
                     rc = scan ? launch_dense<T, 8, 1, true, true, 1, true>(a, p, s)
                               : launch_dense<T, 8, 1, true, true, 1, false>(a, p, s);
                     break;
-                case 2:
+                case 3:
+                    rc = scan ? launch_dense<T, 8, 1, true, true, 1, true, true>(a, p, s)
+                              : launch_dense<T, 8, 1, true, true, 1, false, true>(a, p, s);
+                    break;
+                case 4:
                     rc = scan ? launch_dense<T, 8, 2, true, true, 1, true>(a, p, s)
                               : launch_dense<T, 8, 2, true, true, 1, false>(a, p, s);
+                    break;
+                case 5:
+                    rc = scan ? launch_dense<T, 8, 2, true, true, 1, true, true>(a, p, s)
+                              : launch_dense<T, 8, 2, true, true, 1, false, true>(a, p, s);
                     break;
                 default: rc = dme_set_error(DME_ERR_INTERNAL, "bad J=%d", p.J);
             }

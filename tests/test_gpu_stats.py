@@ -756,6 +756,20 @@ def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big,
     per lane (K = 200: 9 lanes x 3 vectors, 7 rows per wave; K = 48 at 4.1 M rows: 2 lanes x 3
     vectors, 32 rows per wave with a bin word per row slot; K = 400: 10 lanes x 5 vectors).
     K = 3000, 4096, 8000: teams of two or four waves with 3 or 4 vectors per lane."""
+    _narrow_case(oracle, K, N, big, cus, "u16")
+
+
+@pytest.mark.parametrize("K,N,big,cus", [(8, 500_000, 0, 4), (16, 400_000, 200, 4), (104, 300_000, 0, 4),
+                                         (24, 300_001, 70000, 4), (300, 200_000, 0, 2), (100, 60_000, 0, 0),
+                                         (10, 500_000, 0, 4)])
+def test_narrow_int32_rows_bit_exact_vs_oracle(oracle, K, N, big, cus):
+    """int32 rows of 8 to 511 columns take the packed kernel side by side in a wave, with 32-bit LDS
+    counters when they would need more than one round of workgroups (`cus` as above); `big` = 70000:
+    counts beyond 16 bits are settled one by one.  Same bars as for uint16 rows."""
+    _narrow_case(oracle, K, N, big, cus, "i32")
+
+
+def _narrow_case(oracle, K, N, big, cus, dtype):
     from bayespy_amd import _lib
     rng = np.random.default_rng(K * 1000 + N % 1000)
     X = rng.integers(0, 7, size=(N, K), dtype=np.int32)
@@ -764,12 +778,12 @@ def test_narrow_rows_with_32_bit_counters_bit_exact_vs_oracle(oracle, K, N, big,
     X[1::7] = 0                                           # empty rows
     if big:
         X[rng.integers(0, N, 3000), rng.integers(0, K, 3000)] = rng.integers(40, big + 1, 3000)
-    ref = oracle.append_rows(X.astype(np.uint16))
+    ref = oracle.append_rows(X.astype(np.uint16) if dtype == "u16" else X)
     L = _lib.lib()
     try:
         if cus:
             _lib.check(L.dme_set_cu_limit(cus))
-        st, uv, info = _build(X, "u16")
+        st, uv, info = _build(X, dtype)
         torch.cuda.synchronize()
     finally:
         _lib.check(L.dme_set_cu_limit(0))
