@@ -967,8 +967,18 @@ struct PairArgs {
 constexpr int PAIR_BLOCK = 1024, PAIR_RB = 4;
 constexpr int kPairLdsBytes = 150 * 1024;
 
+// (int32 rows: a negative count is reported in status[3] and counts as zero, as in the general kernel)
 __device__ __noinline__ void pair_odd_row(const PairArgs& a, u32 x0, u32 x1, u64* sh_stat) {
-    const u32 total = x0 + x1;
+    if ((int)x0 < 0) {
+        atomicAdd(&sh_stat[3], 1ULL);
+        x0 = 0;
+    }
+    if ((int)x1 < 0) {
+        atomicAdd(&sh_stat[3], 1ULL);
+        x1 = 0;
+    }
+    if ((x0 | x1) == 0) return;
+    const u64 total = (u64)x0 + (u64)x1;
     const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -984,6 +994,8 @@ __device__ __noinline__ void pair_odd_row(const PairArgs& a, u32 x0, u32 x1, u64
     else atomicAdd(&sh_stat[2], 1ULL);
 }
 
+// I32: int32 rows, two to a vector
+template <bool I32>
 __global__ __launch_bounds__(PAIR_BLOCK) void stats_pair_kernel(PairArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32 lds[];
     __shared__ u64 sh_stat[8];
@@ -1007,13 +1019,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void stats_pair_kernel(PairArgs a) {
         if (__builtin_expect(max(x0, x1) < B1, 1)) atomicAdd(&cells[__umul24(x0, B1) + x1], 1u);
         else pair_odd_row(a, x0, x1, sh_stat);
     };
+    auto one32 = [&](u32 x0, u32 x1) {
+        if ((x0 | x1) == 0) return;  // an empty row
+        if (__builtin_expect(max(x0, x1) < B1, 1)) atomicAdd(&cells[__umul24(x0, B1) + x1], 1u);
+        else pair_odd_row(a, x0, x1, sh_stat);  // (a negative count reads as a huge one)
+    };
     auto process = [&](u32x4 (&v)[PAIR_RB]) {
 #pragma unroll
         for (int rb = 0; rb < PAIR_RB; ++rb) {
-            one(v[rb].x);
-            one(v[rb].y);
-            one(v[rb].z);
-            one(v[rb].w);
+            if constexpr (I32) {
+                one32(v[rb].x, v[rb].y);
+                one32(v[rb].z, v[rb].w);
+            } else {
+                one(v[rb].x);
+                one(v[rb].y);
+                one(v[rb].z);
+                one(v[rb].w);
+            }
         }
     };
     if (a.steps > 0) {
@@ -1035,8 +1057,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void stats_pair_kernel(PairArgs a) {
         const u32x4* src = (const u32x4*)lds;
         for (int i = tid; i < (int)(a.part_words >> 2); i += PAIR_BLOCK) dst[i] = src[i];
     }
-    if (tid == 0 && blockIdx.x == 0) atomicAdd(&a.status[0], 4ULL * (u64)a.NV);
-    if (tid >= 1 && tid <= 2 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
+    if (tid == 0 && blockIdx.x == 0) atomicAdd(&a.status[0], (I32 ? 2ULL : 4ULL) * (u64)a.NV);
+    if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
 }
 
@@ -1117,7 +1139,7 @@ __global__ __launch_bounds__(1024) void pair_marginals_kernel(PairArgs a) {
 }
 
 // Returns DME_OK, an error, or -1 when the shape is not this pass's (too many bins, workspace).
-int stats_pair_run(const unsigned short* X, long long NV, u64* hist, long long nbins, u64* histV,
+int stats_pair_run(const void* X, bool i32, long long NV, u64* hist, long long nbins, u64* histV,
                    long long tbins, double* init_acc, u64* status, void* workspace,
                    long long workspace_bytes, hipStream_t s) {
     if (nbins < 2 || nbins > 1024) return -1;
@@ -1134,6 +1156,7 @@ int stats_pair_run(const unsigned short* X, long long NV, u64* hist, long long n
     if (G > cus) G = cus;
     if (G < 1) G = 1;
     if (NV / G >= (1LL << 29)) return -1;  // 32-bit cells
+    if (i32 && nbins > 16384) return -1;   // (the cell index is a 24-bit product)
     PairArgs a{};
     a.X = (const u32x4*)X;
     a.NV = NV;
@@ -1152,11 +1175,16 @@ int stats_pair_run(const unsigned short* X, long long NV, u64* hist, long long n
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel,
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel<false>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes + 1024));
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes + 1024));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(stats_pair_kernel, dim3((unsigned)G), dim3(PAIR_BLOCK), (size_t)(a.part_words * 4), s, a);
+    if (i32)
+        hipLaunchKernelGGL(stats_pair_kernel<true>, dim3((unsigned)G), dim3(PAIR_BLOCK), (size_t)(a.part_words * 4), s, a);
+    else
+        hipLaunchKernelGGL(stats_pair_kernel<false>, dim3((unsigned)G), dim3(PAIR_BLOCK), (size_t)(a.part_words * 4), s, a);
     hipLaunchKernelGGL(pair_sum_kernel, dim3((unsigned)((ncell + 63) / 64)), dim3(64, RED_SLICES), 0, s, a);
     hipLaunchKernelGGL(pair_marginals_kernel, dim3(1), dim3(1024), 0, s, a);
     DME_HIP_CHECK(hipGetLastError());
@@ -1455,13 +1483,15 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     if (sizeof(T) == 2 && !padded && (K == 2 || K == 4) && ld == K && ((uintptr_t)X % 16) == 0 &&
         N >= kSubMinRows)
         sub = (int)(8 / K);
-    if (sub == 4) {  // K = 2: pair counts when the bins allow
-        int rc = stats_pair_run((const unsigned short*)X, N / 4, hist, nbins, histV, tbins, init_acc,
+    // K = 2 (rows back to back, both element types): pair counts when the bins allow
+    if (!padded && K == 2 && ld == 2 && ((uintptr_t)X % 16) == 0 && N >= kSubMinRows) {
+        const long long rpv = 16 / (2 * (long long)sizeof(T));  // rows per vector
+        int rc = stats_pair_run(X, sizeof(T) == 4, N / rpv, hist, nbins, histV, tbins, init_acc,
                                 status, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc > 0) return rc;
         if (rc == DME_OK) {
-            if (N % 4)
-                return stats_dense_run<T>(X + (N / 4) * 8, N % 4, K, ld, hist, nbins, histV, tbins,
+            if (N % rpv)
+                return stats_dense_run<T>(X + (N / rpv) * rpv * 2, N % rpv, K, ld, hist, nbins, histV, tbins,
                                           init_acc, status, workspace, workspace_bytes, stream, false);
             return DME_OK;
         }

@@ -96,8 +96,8 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  * K = 32 768, int32 up to K = 16 384 (from 512 columns on int32 rows run in chunks of 8 columns like
  * uint16 rows; counts of 65536 and more are legal and settled one by one).  Rows that do not fill a
  * wave lie side by side in it, rows of more than 8 vectors per lane are split over teams of 2, 4 or
- * 8 waves.  Narrow uint16 rows that lie back to back from a 16-byte-aligned address: K = 4 as two
- * rows per vector, K = 2 as pair counts (see dme_stats.hip).  Beyond the column limits:
+ * 8 waves.  Narrow rows that lie back to back from a 16-byte-aligned address: uint16 K = 4 as two
+ * rows per vector, K = 2 (both element types) as pair counts (see dme_stats.hip).  Beyond the column limits:
  * DME_ERR_UNSUPPORTED (use the CSR entry).
  * workspace [dev], 256-byte aligned: dme_stats_workspace_bytes(N, K) bytes.
  * ------------------------------------------------------------------------------------------- */

@@ -795,13 +795,16 @@ def _narrow_case(oracle, K, N, big, cus, dtype):
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), exact, rtol=1e-12)
 
 
+@pytest.mark.parametrize("dtype", ["u16", "i32", "i32-negatives"])
 @pytest.mark.parametrize("max_count,max_total", [(40, 80), (20, 30), (33, 35)])
-def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, max_total):
+def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, max_total, dtype):
     """K = 2 in uint16 rows that lie back to back counts the pairs (x0, x1) in LDS and derives
     hist / histV / the mean accumulator from them (stats_pair_kernel); the same rows at a pitch of 4
     take the general kernel.  Both must leave the same histograms and the same status words - also
     when the caller's bounds are too small (counts of 33 against nbins = 21: those rows are settled
-    one by one, status[1] / status[2] report them) - and, within bounds, the oracle's U / V."""
+    one by one, status[1] / status[2] report them) - and, within bounds, the oracle's U / V.
+    int32 rows go two to a vector; "i32-negatives": some negative counts, which both kernels report
+    in status[3] and count as zero."""
     dev = _dev()
     N = 300_003                                            # three rows beyond the last full vector
     rng = np.random.default_rng(max_count)
@@ -809,8 +812,15 @@ def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, 
     X[::5] = (0, 33)
     X[1::7] = 0
     X[2::11] = (17, 0)
-    flat = torch.from_numpy(X.astype(np.uint16)).cuda()
-    wide = torch.zeros((N, 4), dtype=torch.uint16, device="cuda")
+    negatives = dtype == "i32-negatives"
+    if negatives:
+        X[3::13, 0] = -5
+        X[4::17] = (-1, -2)
+    if dtype == "u16":
+        flat = torch.from_numpy(X.astype(np.uint16)).cuda()
+    else:
+        flat = torch.from_numpy(X).cuda()
+    wide = torch.zeros((N, 4), dtype=flat.dtype, device="cuda")
     wide[:, :2] = flat
     a = dev.DeviceStats(2, max_count, max_total)
     a.add_dense(flat, max_count=max_count, max_total=max_total)
@@ -822,10 +832,14 @@ def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, 
     assert torch.equal(a.histV[1:], b.histV[1:])
     assert torch.equal(a.status, b.status)
     np.testing.assert_allclose(a.init_acc.cpu().numpy(), b.init_acc.cpu().numpy(), rtol=1e-12)
-    if max_count >= 33 and max_total >= 35:
+    if negatives:
+        assert int(a.status[3]) == int((X < 0).sum())
+        with pytest.raises(ValueError, match="negative"):
+            a.check()
+    elif max_count >= 33 and max_total >= 35:
         info = a.check()
         assert info["rows"] == N
-        ref = oracle.append_rows(X.astype(np.uint16))
+        ref = oracle.append_rows(X.astype(np.uint16) if dtype == "u16" else X)
         _assert_uv_equal(a.finalize(), ref)
         np.testing.assert_allclose(a.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-10)
     else:
