@@ -1252,13 +1252,42 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
     // of 65 vectors fills 65 of 128 lane slots.  uint16 rows in full vectors may instead take
     // CL = ceil(C / J) lanes with J vectors each, R = 64 / CL rows side by side (K = 200: J = 3,
     // 9 lanes, 7 rows: 175 of 192 slots).
+    // The share of a wave's work that is of use, for rows on CL lanes with J vectors each: a vector is
+    // four steps of a dword (two counts) per lane, and a step is skipped when no lane of the wave has
+    // counts there - the dwords beyond a row's end, when all lanes hold the row's last vector at the
+    // same j (K = 10: one lane per row, the second vector one dword: 5 steps per row instead of the 8
+    // of two lanes per row).
+    auto useful = [&](long long j, long long cl) {
+        const long long taild = p.tail ? (p.tail + 1) / 2 : 4;  // dwords of a row's last vector
+        long long steps = 0;
+        for (long long jj = 0; jj < j; ++jj) {
+            long long m = 0;
+            for (long long cc = 0; cc < cl; ++cc) {
+                const long long v = cc + cl * jj;
+                const long long d = v < C - 1 ? 4 : (v == C - 1 ? taild : 0);
+                if (d > m) m = d;
+            }
+            steps += m;
+        }
+        const long long rr = 64 / cl;
+        const double dwords = 4.0 * (double)(C - 1) + (double)taild;  // of one row
+        return steps ? dwords * (double)rr / (64.0 * (double)steps) : 0.0;
+    };
     if (E == 8 && sub == 1 && C <= (pack ? 2 : 5) * 64) {
-        double best = p.multi ? (double)(C * p.R) / 64.0 : (double)C / (64.0 * (double)jtot);
+        // (the packed int32 kernel counts whole vectors: its two-vector variant is the slower one)
+        double best = !p.multi ? (double)C / (64.0 * (double)jtot)
+                      : pack   ? (double)(C * p.R) / 64.0
+                               : useful(1, C);
         for (int j = 1; j <= (pack ? 2 : 5); ++j) {
             const long long cl = (C + j - 1) / j;
             if (cl > 64 || (p.multi && j == 1)) continue;
+            // a lane per row with three or more vectors: every load instruction of the wave touches
+            // every cache line of its rows (K = 20: 2.73 TB/s against 3.92 on three lanes per row)
+            if (cl == 1 && j > 2) continue;
             const long long rr = 64 / cl;
-            const double u = (double)(C * rr) / (64.0 * j);
+            // 4 and 5 vectors per lane run fewer threads
+            const double u = pack ? (double)(C * rr) / (64.0 * j)
+                                  : useful(j, cl) * (j == 4 ? 0.95 : j == 5 ? 0.85 : 1.0);
             // (the packed int32 kernel of two vectors per lane runs 768 threads: K = 100 measured 4.45
             // TB/s with one vector per lane on 52 lanes against 3.67 with two on 63)
             if (u > best * (pack ? 1.3 : 1.08)) {
