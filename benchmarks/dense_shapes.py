@@ -18,8 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-DEFAULT = ("2:u16:60,8:u16:100,16:u16:100,64:u16:100,104:u16:100,200:u16:100,512:u16,1000:u16,1000:i32,"
-           "2048:u16,3000:u16,4096:u16,4096:i32")
+DEFAULT = ("2:u16:60,4:u16:60,8:u16:100,16:u16:100,32:u16:100,64:u16:100,104:u16:100,200:u16:100,320:u16:200,"
+           "400:u16:200,512:u16,600:u16,768:u16,1000:u16,1000:i32,1001:u16,1536:u16,2048:u16,2048:i32,2300:u16,"
+           "2560:u16,3000:u16,4096:u16,4096:i32,8192:u16,16384:u16,32768:u16,8192:i32,16384:i32")
 
 
 def main():
