@@ -48,9 +48,19 @@ constexpr int BBLOCK = 1024;           // bucket / reduce kernels
 constexpr int IMAGE_LDS_BYTES = 112 * 1024;
 constexpr int WTAB = 2048;             // row totals whose weight 1 / (1 + n) is tabulated in LDS
 constexpr int OVF = 2048;              // slots of an image's overflow table (counts beyond the bins)
+#ifndef DME_CSR2_PIECES_PER_CU
+#define DME_CSR2_PIECES_PER_CU 4
+#endif
+
+#ifndef DME_CSR3_WGS_PER_CU
+#define DME_CSR3_WGS_PER_CU 2
+#endif
 
 struct Plan {
     int sh, CB, NB, BL, AC, G, W;
+    int G3;                       // workgroups of the tile partition kernel
+    long long chunks_per_wg3;     // chunk ids each of them owns
+    long long off_flag, off_rstart;
     long long rows_per_wg, max_chunks;
     long long image_bytes;
     // workspace offsets (bytes)
@@ -82,12 +92,23 @@ inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan*
     if (G < 1) G = 1;
     p->G = (int)G;
     p->rows_per_wg = (N + G - 1) / G;
-    p->W = cus;
+    p->W = cus * DME_CSR2_PIECES_PER_CU;
     // every record fills a slot; every (wave, bucket) pair may leave one chunk partly filled
     p->max_chunks = (nnz + CHUNK - 1) / CHUNK + G * ((long long)PWAVES * p->NB + 2) + 64;
+    // the tile kernel: G3 workgroups with ceil(nnz / G3) entries each at most; every bucket's stream may
+    // leave one chunk partly filled
+    long long G3 = (nnz + 4LL * 4096 - 1) / (4LL * 4096);
+    if (G3 > (long long)cus * DME_CSR3_WGS_PER_CU) G3 = (long long)cus * DME_CSR3_WGS_PER_CU;
+    if (G3 < 1) G3 = 1;
+    p->G3 = (int)G3;
+    const long long per3 = (nnz + G3 - 1) / G3;
+    p->chunks_per_wg3 = (per3 + CHUNK - 1) / CHUNK + p->NB + 1;
+    if (G3 * p->chunks_per_wg3 > p->max_chunks) p->max_chunks = G3 * p->chunks_per_wg3;
     if (p->max_chunks >= (1LL << 21)) return false;  // sorted entries hold 21-bit chunk ids
     long long o = 0;
     p->off_head = o;     o = align256(o + 256);
+    p->off_flag = o;     o = align256(o + 256);
+    p->off_rstart = o;   o = align256(o + 8 * (G3 + 1));
     p->off_cbucket = o;  o = align256(o + p->max_chunks);
     p->off_cfill = o;    o = align256(o + 2 * p->max_chunks);
     p->off_sorted = o;   o = align256(o + 4 * p->max_chunks);
@@ -114,6 +135,7 @@ struct PartArgs {
     u64* histV;
     double* init_acc;
     u64* status;
+    const u32* rowptr_bad;  // set by csr3_check_kernel: the row-wise kernel below runs only then
 };
 
 // Per-wave staging in LDS.  All of it is private to one wave: LDS serves a wave's accesses in
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
     __shared__ u32 wg_next;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.rowptr_bad && *a.rowptr_bad == 0) return;  // a well-formed rowptr: csr3_part_kernel has done the work
     WaveStage& st = stages[wave];
     for (int i = tid; i < a.TB; i += PBLOCK) tb[i] = 0;
     if (tid < 8) sh_stat[tid] = 0;
@@ -437,6 +460,482 @@ __global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
     if (tid == 6 && sh_stat[6]) atomicAdd(&a.status[6], sh_stat[6]);
 }
 
+
+// =====================================================================================================
+// Tile partition kernel (round 3).  The row-wise kernel above keeps one wave on one row: 27 % of the
+// lanes idle at ~47 entries per row, five dependent LDS round trips per row, one row of loads in flight
+// (4.85 ms for the 12.5 M-row shard of BASELINE configs[3]; SQ_WAIT_ANY 63 % of the wave cycles).  Here a
+// 512-thread workgroup takes the entries themselves, TILE = 4096 consecutive entries at a time, eight per
+// thread whatever the row lengths:
+//   P1  thread j looks at row j of the tile's row window (512 row pointers): which rows start in the
+//       tile, which row straddles its end; the eight counts of every thread go into a prefix sum
+//   P2  prefix sums to LDS (PX); every row writes its window index at the position where it starts (F);
+//       every entry takes its number in its bucket's run with one returning LDS add; waves 0 / 1 add up
+//       what the first / last row of the tile holds outside the tile (read from L2, the neighbour tile
+//       has just loaded or is about to load it)
+//   P3  row totals = differences of PX (+ the outside parts): histV, maxima, row count; lane b of wave 0
+//       turns the bucket counts into offsets and takes chunk ids for bucket b's run; every entry finds
+//       its row: the largest F at or before it (running maximum in the thread, DPP max-scan in the wave)
+//   P4  records {column-in-bucket | count | row total} go to their place in the bucket-ordered staging
+//       area; what a record cannot hold goes to global atomics, as in the row-wise kernel
+//   P5  wave w writes the runs of buckets w, w + 8, ... to the buckets' streams: consecutive lanes,
+//       consecutive records (a run of a 4096-entry tile is ~84 records at 49 buckets)
+// Four barriers per tile; the loads of the next tile (entries and row pointers) are issued in P2.
+// Rows are OWNED (counted, added to histV) by the tile their index falls to: tile boundaries advance in
+// entries (<= TILE) and in rows (<= 512), whichever comes first, so empty rows and one-entry rows cannot
+// stall it.  Workgroup g owns the entries [E0 + g S, E0 + (g + 1) S) of the matrix, E0 = rowptr[0],
+// S = ceil((rowptr[N] - E0) / G): its chunk ids are a fixed range of ceil(S / CHUNK) + NB + 1, and the
+// row that holds its first entry comes from csr3_check_kernel, which also proves rowptr well-formed
+// (non-negative, non-decreasing, within nnz).  A rowptr that is not leaves everything to the row-wise
+// kernel: rows that overlap or run backwards have no place in a partition of the entries.
+// =====================================================================================================
+constexpr int T3 = 512;               // threads of a tile workgroup
+constexpr int T3W = T3 / 64;
+constexpr int EPT = 8;                // entries per thread
+constexpr int TILE = T3 * EPT;        // entries per tile
+constexpr int RW = T3;                // rows of a tile's window (one per thread)
+constexpr u32 HUGE_V = 1u << 19;      // counts from here on: row totals are added up in 64 bits, row by row
+
+struct TileArgs {
+    PartArgs a;
+    u32* flag;             // written by the check kernel: != 0 = malformed rowptr
+    long long* rstart;     // [G + 1] number of rows that start before E0 + g S; [G]: before rowptr[N]
+    int G;
+    long long chunks_per_wg;
+};
+
+__global__ __launch_bounds__(256) void csr3_check_kernel(const long long* rowptr, long long N, long long nnz,
+                                                         int G, u32* flag, long long* rstart) {
+    const long long E0 = rowptr[0], E1 = rowptr[N];
+    long long span = E1 - E0;
+    if (span < 0) span = 0;
+    long long S = (span + G - 1) / G;
+    if (S < 1) S = 1;
+    bool bad = false;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += stride) {
+        const long long p0 = rowptr[j], p1 = rowptr[j + 1];
+        if (p0 < 0 || p1 < p0 || p1 > nnz) {
+            bad = true;
+        } else if (p1 > p0 && p0 >= E0 && p1 <= E1) {
+            // the boundaries E0 + g S in (p0, p1]: row j is the last one that starts before them
+            long long g_lo = (p0 - E0) / S + 1, g_hi = (p1 - E0) / S;
+            if (g_hi > G - 1) g_hi = G - 1;
+            for (long long g = g_lo; g <= g_hi; ++g) rstart[g] = j + 1;
+            if (p1 == E1) rstart[G] = j + 1;
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__device__ __forceinline__ u32 wave_incl_scan_max_u32(u32 v) {
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+// the value of the lane below (lane 0: 0)
+__device__ __forceinline__ u32 wave_shr1_u32(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);  // wave_shr:1
+}
+
+typedef u32 u32x4v __attribute__((ext_vector_type(4)));
+typedef u32x4v u32x4v_u __attribute__((aligned(4)));
+
+struct TileLds {
+    u32 F[TILE];          // window index + 1 of the row that starts at an entry position (0: none)
+    u32 PX[TILE + 4];     // exclusive prefix sums of the tile's counts; from P4 on: the staged records
+    u64 RT[RW];           // row totals of the window's rows
+    u32 cnt[MAXB];        // records of the tile per bucket (P2), zeroed again in P3
+    u32 off[MAXB + 1];    // the buckets' runs in the staging area
+    u32 len[MAXB];        // records written to the bucket's stream so far
+    u32 lenold[MAXB];     // ... before this tile
+    u32 cur[MAXB];        // id of the stream's last chunk
+    u32 curold[MAXB];
+    u32 newbase[MAXB];    // first of the chunk ids taken for this tile's run
+    u32 wsum[T3W], wmax[T3W], wrows[T3W];
+    u32 straddle;         // window index + 1 of the row that runs over the tile's end
+    u32 wg_next;          // chunk ids taken from the workgroup's range
+    u32 huge;             // a count >= HUGE_V in the tile
+    u32 pad;
+    long long tail_hi;    // where that row ends
+    u64 head_extra, tail_extra;
+    u64 stat[8];
+};
+
+__global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const PartArgs& a = ta.a;
+    if (*ta.flag != 0) return;  // malformed rowptr: the row-wise kernel takes the call
+    TileLds& L = *(TileLds*)lds_raw;
+    u32* tb = (u32*)(lds_raw + sizeof(TileLds));  // [TB] row-total bins
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = ta.G, g = blockIdx.x;
+    const long long N = a.N;
+    const long long E0 = a.rowptr[0], E1 = a.rowptr[N];
+    long long S = (E1 - E0 + G - 1) / G;
+    if (S < 1) S = 1;
+    long long A = E0 + (long long)g * S;
+    if (A > E1) A = E1;
+    long long Aend = A + S;
+    if (Aend > E1) Aend = E1;
+    const bool last = g == G - 1;
+    if (A >= E1 && !last) return;  // nothing of the matrix falls to this workgroup
+
+    for (int i = tid; i < TILE; i += T3) L.F[i] = 0;
+    for (int i = tid; i < a.TB; i += T3) tb[i] = 0;
+    if (tid < MAXB) {
+        L.cnt[tid] = 0;
+        L.len[tid] = 0;
+        L.cur[tid] = 0xFFFFFFFFu;
+    }
+    if (tid < 8) L.stat[tid] = 0;
+    if (tid == 0) {
+        L.straddle = 0;
+        L.wg_next = 0;
+        L.huge = 0;
+        L.tail_hi = 0;
+        L.head_extra = 0;
+        L.tail_extra = 0;
+    }
+    const long long cbase = (long long)g * ta.chunks_per_wg;
+    long long climit = cbase + ta.chunks_per_wg;
+    if (climit > a.max_chunks) climit = a.max_chunks;
+
+    long long jown = A >= E1 ? ta.rstart[G] : ta.rstart[g];  // first row this workgroup owns
+    if (jown > N) jown = N;
+    long long jb = jown;                                       // first row of the window
+    if (A < E1 && jown >= 1 && a.rowptr[jown] > A) jb = jown - 1;  // the row that holds entry A began earlier
+    long long apos = A;
+
+    const u32 cmask = (1u << a.sh) - 1;
+    const u32 vmax = a.nbins < (long long)VLIM ? (u32)a.nbins : VLIM;  // counts a record and hist hold
+    u32 maxv = 0;
+    u64 maxt = 0, bad = 0, big = 0, nrows = 0, over = 0, pool = 0;
+
+    // ---- loads of a tile: three row pointers and eight entries per thread -------------------------------
+    auto load_window = [&](long long jb_, long long& q0, long long& q1, long long& qrw) {
+        long long j0 = jb_ + tid, j1 = j0 + 1, jr = jb_ + RW;
+        if (j0 > N) j0 = N;
+        if (j1 > N) j1 = N;
+        if (jr > N) jr = N;
+        q0 = a.rowptr[j0];
+        q1 = a.rowptr[j1];
+        qrw = a.rowptr[jr];
+    };
+    auto load_entries = [&](long long ap, u32 (&c)[EPT], u32 (&v)[EPT]) {
+        const long long e = ap + (long long)tid * EPT;
+#pragma unroll
+        for (int h = 0; h < EPT / 4; ++h) {
+            const long long eh = e + 4 * h;
+            if (eh + 3 < E1) {
+                const u32x4v cc = __builtin_nontemporal_load((const u32x4v_u*)(a.colidx + eh));
+                const u32x4v vv = __builtin_nontemporal_load((const u32x4v_u*)(a.vals + eh));
+                c[4 * h] = cc.x; c[4 * h + 1] = cc.y; c[4 * h + 2] = cc.z; c[4 * h + 3] = cc.w;
+                v[4 * h] = vv.x; v[4 * h + 1] = vv.y; v[4 * h + 2] = vv.z; v[4 * h + 3] = vv.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = eh + i < E1;
+                    c[4 * h + i] = in ? (u32)a.colidx[eh + i] : 0u;
+                    v[4 * h + i] = in ? (u32)a.vals[eh + i] : 0u;
+                }
+            }
+        }
+    };
+    // sum of the positive counts in [lo, hi) by one wave (what a row holds outside the tile)
+    auto wave_row_part = [&](long long lo, long long hi) -> u64 {
+        u64 s = 0;
+        for (long long q = lo + lane; q < hi; q += 64) {
+            const int x = a.vals[q];
+            s += (u64)(x > 0 ? x : 0);
+        }
+        return dme_wave_sum_u64(s);
+    };
+
+    long long nq0, nq1, nqrw;
+    u32 nc[EPT], nv[EPT];
+    load_window(jb, nq0, nq1, nqrw);
+    load_entries(apos, nc, nv);
+    __syncthreads();
+
+    while (true) {
+        const long long Q0 = nq0, Q1 = nq1, QRW = nqrw;
+        u32 c[EPT], v[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            c[i] = nc[i];
+            v[i] = nv[i];
+        }
+        // ---- the tile: entries [apos, anext), rows [jown, jownN) ---------------------------------------
+        long long alim = apos + TILE;
+        if (alim > Aend) alim = Aend;
+        const bool exhausted = jb + RW < N && QRW < alim;  // the window's rows end before the entries do
+        const long long anext = exhausted ? QRW : alim;
+        const int n_ent = (int)(anext - apos);
+        const bool fin = anext >= E1;                      // the matrix' entries are done
+        const int jrel = (int)(jown - jb);                 // 1: window row 0 began before the tile
+        const bool vrow = jb + tid < N;
+        const bool owned = vrow && tid >= jrel && (exhausted || Q0 < anext || (last && fin));
+        // positions relative to the tile, clamped to [-1, n_ent + 1]
+        long long sl = Q0 - apos, tl = Q1 - apos;
+        const int s_rel = sl < 0 ? -1 : (sl > n_ent ? n_ent + 1 : (int)sl);
+        const int t_rel = tl < 0 ? -1 : (tl > n_ent ? n_ent + 1 : (int)tl);
+        const bool over_end = vrow && Q0 < anext && Q1 > anext;  // at most one row
+
+        // ---- P1 ------------------------------------------------------------------------------------------
+        u32 vp[EPT];
+        u32 tsum = 0;
+        bool hg = false;
+        const int k0 = tid * EPT;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool in = k0 + i < n_ent;
+            const int x = (int)v[i];
+            u32 pv = in && x > 0 ? (u32)x : 0u;
+            hg |= pv >= HUGE_V;
+            if (pv > HUGE_V) pv = HUGE_V;
+            vp[i] = tsum;  // exclusive inside the thread
+            tsum += pv;
+        }
+        const u32 incl = dme_wave_incl_scan_u32(tsum);
+        if (lane == 63) L.wsum[wave] = incl;
+        {
+            const u64 ob = __ballot(owned);
+            if (lane == 0) L.wrows[wave] = (u32)__popcll(ob);
+            if (__any(hg) && lane == 0) L.huge = 1;
+        }
+        if (over_end) {
+            L.straddle = (u32)tid + 1;
+            L.tail_hi = Q1;
+        }
+        __syncthreads();  // B1
+
+        // ---- P2 ------------------------------------------------------------------------------------------
+        u32 rows_owned = 0, wbase = 0;
+#pragma unroll
+        for (int w = 0; w < T3W; ++w) {
+            const u32 r = L.wrows[w], x = L.wsum[w];
+            rows_owned += r;
+            wbase += w < wave ? x : 0u;
+        }
+        const u32 strad = L.straddle;
+        const bool has_huge = L.huge != 0;
+        const long long jownN = jown + rows_owned;
+        const long long jbN = strad ? jb + (long long)strad - 1 : jownN;
+        const bool cont = anext < Aend || (last && jownN < N);
+        if (cont) {
+            load_window(jbN, nq0, nq1, nqrw);
+            if (anext < Aend) load_entries(anext, nc, nv);
+        }
+        {
+            const u32 tbase = wbase + incl - tsum;  // entries before this thread
+            u32x4v* px = (u32x4v*)&L.PX[k0];
+            px[0] = u32x4v{tbase + vp[0], tbase + vp[1], tbase + vp[2], tbase + vp[3]};
+            px[1] = u32x4v{tbase + vp[4], tbase + vp[5], tbase + vp[6], tbase + vp[7]};
+            if (tid == T3 - 1) L.PX[TILE] = tbase + tsum;
+        }
+        if (vrow && s_rel >= 0 && s_rel < n_ent) atomicMax(&L.F[s_rel], (u32)tid + 1);
+        bool ok[EPT];
+        u32 rank[EPT];
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool in = k0 + i < n_ent;
+            ok[i] = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
+            rank[i] = 0;
+            if (ok[i]) rank[i] = atomicAdd(&L.cnt[c[i] >> a.sh], 1u);
+        }
+        if (wave == 0 && jrel == 1) {  // window row 0 began before the tile: its entries in front of it
+            const long long h0 = (long long)((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)Q0) |
+                                             ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)Q0 >> 32)) << 32));
+            const u64 x = wave_row_part(h0, apos);
+            if (lane == 0) L.head_extra = x;
+        }
+        if (wave == 1 && strad) {      // the row that runs over the tile's end: its entries behind it
+            const u64 x = wave_row_part(anext, L.tail_hi);
+            if (lane == 0) L.tail_extra = x;
+        }
+        __syncthreads();  // B2
+
+        // ---- P3 ------------------------------------------------------------------------------------------
+        if (wave == 0) {  // lane = bucket: the runs of the staging area, chunk ids for what they add
+            const u32 m = L.cnt[lane];
+            const u32 inc = dme_wave_incl_scan_u32(m);
+            L.off[lane] = inc - m;
+            if (lane == 63) L.off[MAXB] = inc;
+            L.cnt[lane] = 0;
+            const u32 lo = L.len[lane];
+            L.lenold[lane] = lo;
+            L.curold[lane] = L.cur[lane];
+            if (m > 0) {
+                const u32 firstnew = (lo + CHUNK - 1) >> 10;        // chunks the stream has opened so far
+                const u32 lastcn = (lo + m - 1) >> 10;              // chunk number of the run's last record
+                const u32 nnew = lastcn + 1 > firstnew ? lastcn + 1 - firstnew : 0u;
+                if (nnew) {
+                    const long long id0 = cbase + (long long)atomicAdd(&L.wg_next, nnew);
+                    u32 nb32 = 0xFFFFFFFFu, lastid = 0xFFFFFFFFu;
+                    if (id0 + nnew <= climit) {
+                        nb32 = (u32)id0;
+                        lastid = (u32)(id0 + nnew - 1);
+                        for (u32 q = 0; q < nnew; ++q) {
+                            a.chunk_bucket[id0 + q] = (unsigned char)lane;
+                            a.chunk_fill[id0 + q] = (unsigned short)CHUNK;  // the stream's last one: corrected at the end
+                        }
+                    } else {
+                        pool++;  // cannot happen with a well-formed rowptr: the range is sized for S entries
+                    }
+                    L.newbase[lane] = nb32;
+                    L.cur[lane] = lastid;
+                }
+                L.len[lane] = lo + m;
+            }
+        }
+        if (vrow && (owned || (tid == 0 && jrel == 1))) {  // row totals (DE/dme.py:121 sum(row))
+            u64 total;
+            if (!has_huge) {
+                const int s0 = s_rel < 0 ? 0 : (s_rel > n_ent ? n_ent : s_rel);
+                const int t0 = t_rel < 0 ? 0 : (t_rel > n_ent ? n_ent : t_rel);
+                total = (u64)(L.PX[t0] - L.PX[s0]);
+                if (tid == 0 && jrel == 1) total += L.head_extra;
+                if (strad == (u32)tid + 1) total += L.tail_extra;
+            } else {  // a count of 2^19 or more somewhere in the tile: this row's counts one by one, in 64 bits
+                total = 0;
+                for (long long q = Q0; q < Q1; ++q) {
+                    const int x = a.vals[q];
+                    total += (u64)(x > 0 ? x : 0);
+                }
+            }
+            L.RT[tid] = total;
+            if (owned) {
+                nrows++;
+                if (total > 0) {
+                    maxt = total > maxt ? total : maxt;
+                    if (total < (u64)a.TB) atomicAdd(&tb[total], 1u);
+                    else if ((long long)total < a.tbins) atomicAdd(&a.histV[total], 1ULL);
+                    else over++;
+                }
+            }
+        }
+        u32 f[EPT];
+        u32 wexcl;
+        {
+            const u32x4v* fp = (const u32x4v*)&L.F[k0];
+            const u32x4v f0 = fp[0], f1 = fp[1];
+            u32x4v* fz = (u32x4v*)&L.F[k0];
+            fz[0] = u32x4v{0u, 0u, 0u, 0u};  // for the next tile (its rows write after two more barriers)
+            fz[1] = u32x4v{0u, 0u, 0u, 0u};
+            f[0] = f0.x;
+            f[1] = max(f[0], f0.y);
+            f[2] = max(f[1], f0.z);
+            f[3] = max(f[2], f0.w);
+            f[4] = max(f[3], f1.x);
+            f[5] = max(f[4], f1.y);
+            f[6] = max(f[5], f1.z);
+            f[7] = max(f[6], f1.w);
+            const u32 winc = wave_incl_scan_max_u32(f[7]);
+            wexcl = wave_shr1_u32(winc);
+            if (lane == 63) L.wmax[wave] = winc;
+        }
+        __syncthreads();  // B3
+
+        // ---- P4 ------------------------------------------------------------------------------------------
+        if (tid == 0) {
+            L.straddle = 0;
+            L.huge = 0;
+        }
+#pragma unroll
+        for (int w = 0; w < T3W; ++w) {
+            const u32 x = L.wmax[w];
+            wexcl = max(wexcl, w < wave ? x : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const bool in = k0 + i < n_ent;
+            if (!in || v[i] == 0) continue;
+            u32 ri = max(f[i], wexcl);
+            ri = ri > 0 ? ri - 1 : 0u;  // entries in front of the first row start: window row 0
+            const u64 total = L.RT[ri];
+            if (ok[i]) {
+                maxv = v[i] > maxv ? v[i] : maxv;
+                u32 rec = 0;  // a record with count 0 is skipped by the bucket pass
+                if (total < (u64)TLIM) {
+                    rec = (c[i] & cmask) | (v[i] << COLBITS) | ((u32)total << (COLBITS + VBITS));
+                } else {      // a record cannot hold the row total
+                    atomicAdd(&a.hist[(long long)c[i] * a.nbins + v[i]], 1ULL);
+                    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+                    atomicAdd(&a.init_acc[c[i]], __dmul_rn((double)v[i], w));
+                }
+                L.PX[L.off[c[i] >> a.sh] + rank[i]] = rec;
+            } else if ((int)v[i] < 0 || c[i] >= (u32)a.K) {
+                bad++;
+            } else {  // a count the record (>= 256) or the caller's histogram (>= nbins) cannot hold
+                maxv = v[i] > maxv ? v[i] : maxv;
+                if ((long long)v[i] < a.nbins) atomicAdd(&a.hist[(long long)c[i] * a.nbins + v[i]], 1ULL);
+                else big++;  // reported, not counted; the mean accumulator still takes it
+                const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+                atomicAdd(&a.init_acc[c[i]], __dmul_rn((double)v[i], w));
+            }
+        }
+        __syncthreads();  // B4
+
+        // ---- P5: the runs leave for the buckets' streams -----------------------------------------------------
+        for (int b = wave; b < a.NB; b += T3W) {
+            const u32 o = L.off[b], m = L.off[b + 1] - o;
+            if (m == 0) continue;
+            const u32 lo = L.lenold[b], curold = L.curold[b], nbase = L.newbase[b];
+            const u32 firstnew = (lo + CHUNK - 1) >> 10;
+            for (u32 i = lane; i < m; i += 64) {
+                const u32 rec = L.PX[o + i];
+                const u32 p = lo + i;
+                const u32 cn = p >> 10;
+                u32 id;
+                if (cn < firstnew) id = curold;
+                else id = nbase == 0xFFFFFFFFu ? nbase : nbase + (cn - firstnew);
+                if (id != 0xFFFFFFFFu) a.chunks[(long long)id * CHUNK + (p & (CHUNK - 1))] = rec;
+            }
+        }
+        if (!cont) break;
+        apos = anext;
+        jb = jbN;
+        jown = jownN;
+    }
+
+    // ---- the streams' last chunks, the statistics of the pass ----------------------------------------------
+    __syncthreads();
+    if (tid < a.NB) {
+        const u32 n = L.len[tid], id = L.cur[tid];
+        if (n > 0 && (n & (CHUNK - 1)) && id != 0xFFFFFFFFu) a.chunk_fill[id] = (unsigned short)(n & (CHUNK - 1));
+    }
+    nrows = dme_wave_sum_u64(nrows);
+    bad = dme_wave_sum_u64(bad);
+    big = dme_wave_sum_u64(big);
+    over = dme_wave_sum_u64(over);
+    pool = dme_wave_sum_u64(pool);
+    const u32 mv = dme_wave_max_u32(maxv);
+    maxt = dme_wave_max_u64(maxt);
+    if (lane == 0) {
+        if (nrows) atomicAdd(&L.stat[0], nrows);
+        if (big) atomicAdd(&L.stat[1], big);
+        if (over) atomicAdd(&L.stat[2], over);
+        if (bad) atomicAdd(&L.stat[3], bad);
+        if (mv) atomicMax(&L.stat[4], (u64)mv);
+        if (maxt) atomicMax(&L.stat[5], maxt);
+        if (pool) atomicAdd(&L.stat[6], pool);
+    }
+    __syncthreads();
+    for (int i = tid; i < a.TB; i += T3) {
+        const u32 cn = tb[i];
+        if (cn) atomicAdd(&a.histV[i], (u64)cn);
+    }
+    if (tid <= 3 && L.stat[tid]) atomicAdd(&a.status[tid], L.stat[tid]);
+    if (tid >= 4 && tid <= 5 && L.stat[tid]) atomicMax(&a.status[tid], L.stat[tid]);
+    if (tid == 6 && L.stat[6]) atomicAdd(&a.status[6], L.stat[6]);
+}
+
 // Lists the chunks bucket by bucket (a counting sort over three small launches):
 // sorted[i] = chunk id | (records in the chunk - 1) << IDBITS for the chunks that hold records,
 // bstart[b] = first position of bucket b in `sorted`, bstart[NB] = number of listed chunks.
@@ -561,14 +1060,14 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
             for (int i = tid; i < a.AC * CB; i += BBLOCK) acc[i] = 0.0;
             __syncthreads();
             const long long kbase = (long long)b << a.sh;
-            auto one = [&](u32 rec) {
+            // Counts beyond the bins and row totals beyond the weight table: one record at a time,
+            // only in waves that hold such a record (head-of-vocabulary columns, very long rows).
+            auto rare_one = [&](u32 rec) {
                 const u32 v = (rec >> COLBITS) & (VLIM - 1);
                 if (v == 0) return;
                 const u32 cl = rec & cmask;
                 const u32 tot = rec >> (COLBITS + VBITS);
-                if (v <= (u32)a.BL) {
-                    atomicAdd(&h[(v - 1) * CB + cl], 1u);  // bin-major: bank = column
-                } else {
+                if (v > (u32)a.BL) {
                     const u32 key = ((cl << VBITS) | v) + 1u;
                     u32 slot = (key * 2654435761u) >> (32 - 11);  // OVF = 2^11
                     bool placed = false;
@@ -582,35 +1081,67 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                     }
                     if (!placed) atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], 1ULL);  // table crowded
                 }
-                const double w = tot < (u32)WTAB ? wtab[tot] : __ddiv_rn(1.0, __dadd_rn(1.0, (double)tot));
-                __hip_atomic_fetch_add(&acc[((u32)tid & acmask) * CB + cl], __dmul_rn((double)v, w),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tot >= (u32)WTAB) {
+                    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)tot));
+                    __hip_atomic_fetch_add(&acc[((u32)tid & acmask) * CB + cl], __dmul_rn((double)v, w),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             };
             // a chunk is CHUNK = BBLOCK records: one per thread.  Two register buffers of eight chunks:
-            // the loads of the next eight are in flight while the current eight are counted.
+            // the loads of the next eight are in flight while the current eight are counted.  The eight
+            // records of a buffer go through the LDS pipe side by side (eight weight reads, one wait,
+            // eight counter adds, eight accumulator adds): taken one record at a time, every record paid
+            // the latency of its own weight read (2.18 ms for the 12.5 M-row shard; the LDS operations
+            // themselves need 0.6 ms, benchmarks/micro/lds_atomics.hip).
             constexpr int D = 8;
+            u32 vzero;  // a zero the compiler cannot see: keeps the chunk list's loads vector loads
+            asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
             auto fetch = [&](u32 ci, u32 (&rec)[D]) {
                 u32 se[D];
 #pragma unroll
-                for (int q = 0; q < D; ++q) se[q] = ci + q < seg_end ? a.sorted[ci + q] : 0u;
+                for (int q = 0; q < D; ++q) se[q] = ci + q < seg_end ? a.sorted[ci + q + vzero] : 0u;
 #pragma unroll
                 for (int q = 0; q < D; ++q)
                     rec[q] = (ci + q < seg_end && (u32)tid <= (se[q] >> IDBITS))
                                  ? __builtin_nontemporal_load(a.chunks + (long long)(se[q] & ((1u << IDBITS) - 1)) * CHUNK + tid)
                                  : 0u;
             };
+            double* const acc_mine = acc + ((u32)tid & acmask) * CB;
+            auto count = [&](const u32 (&rec)[D]) {
+                u32 v[D], cl[D];
+                double w[D];
+                bool rare = false;
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    v[q] = (rec[q] >> COLBITS) & (VLIM - 1);
+                    cl[q] = rec[q] & cmask;
+                    const u32 tot = rec[q] >> (COLBITS + VBITS);
+                    rare |= v[q] > (u32)a.BL || tot >= (u32)WTAB;
+                    w[q] = wtab[tot < (u32)WTAB ? tot : 0u];
+                }
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+                    if (v[q] - 1u < (u32)a.BL) atomicAdd(&h[(v[q] - 1) * CB + cl[q]], 1u);  // bin-major: bank = column
+#pragma unroll
+                for (int q = 0; q < D; ++q)
+                    if (v[q] != 0 && (rec[q] >> (COLBITS + VBITS)) < (u32)WTAB)
+                        __hip_atomic_fetch_add(&acc_mine[cl[q]], __dmul_rn((double)v[q], w[q]), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__any(rare)) {
+#pragma unroll
+                    for (int q = 0; q < D; ++q) rare_one(rec[q]);
+                }
+            };
             u32 ra[D], rb[D];
             u32 ci = pos;
             fetch(ci, ra);
             while (true) {
                 fetch(ci + D, rb);
-#pragma unroll
-                for (int q = 0; q < D; ++q) one(ra[q]);
+                count(ra);
                 ci += D;
                 if (ci >= seg_end) break;
                 fetch(ci + D, ra);
-#pragma unroll
-                for (int q = 0; q < D; ++q) one(rb[q]);
+                count(rb);
                 ci += D;
                 if (ci >= seg_end) break;
             }
@@ -713,6 +1244,16 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     a.chunks = (u32*)(ws + p.off_chunks);
     a.hist = hist; a.histV = histV; a.init_acc = init_acc; a.status = status;
     DME_HIP_CHECK(hipMemsetAsync(a.chunk_fill, 0, 2 * p.max_chunks, s));
+    // flag and rstart lie side by side: one memset
+    DME_HIP_CHECK(hipMemsetAsync(ws + p.off_flag, 0, (size_t)(p.off_rstart - p.off_flag) + 8 * ((size_t)p.G3 + 1), s));
+    TileArgs ta{};
+    ta.flag = (u32*)(ws + p.off_flag);
+    ta.rstart = (long long*)(ws + p.off_rstart);
+    ta.G = p.G3;
+    ta.chunks_per_wg = p.chunks_per_wg3;
+    a.rowptr_bad = ta.flag;
+    ta.a = a;
+    const size_t lds_tile = sizeof(TileLds) + 4 * (size_t)a.TB;
     const size_t lds_part = sizeof(WaveStage) * PWAVES + 4 * (size_t)a.TB;
     static bool attr_set[64] = {};
     int dev = 0;
@@ -724,9 +1265,18 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr2_bucket_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           IMAGE_LDS_BYTES + 8 * WTAB));
+        DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr3_part_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(sizeof(TileLds) + 4 * TBL)));
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(csr2_part_kernel, dim3(p.G), dim3(PBLOCK), lds_part, s, a);
+    {
+        long long cg = (N + 255) / 256;
+        if (cg > 2048) cg = 2048;
+        hipLaunchKernelGGL(csr3_check_kernel, dim3((unsigned)cg), dim3(256), 0, s, rowptr, N, nnz, p.G3, ta.flag, ta.rstart);
+    }
+    hipLaunchKernelGGL(csr3_part_kernel, dim3(p.G3), dim3(T3), lds_tile, s, ta);
+    hipLaunchKernelGGL(csr2_part_kernel, dim3(p.G), dim3(PBLOCK), lds_part, s, a);  // leaves at once unless rowptr is malformed
     u32* sorted = (u32*)(ws + p.off_sorted);
     u32* bstart = (u32*)(ws + p.off_bstart);
     u32* bcount = (u32*)(ws + p.off_bcount);

@@ -108,6 +108,82 @@ def test_config4_bag_of_words_csr(oracle):
     assert out["n_iters"] == ref["n_iters"]
 
 
+def _bow_generator():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks", "bow_csr.py")
+    spec = importlib.util.spec_from_file_location("bow_csr", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.generate
+
+
+def test_config4_csr_shard_scale_properties():
+    """C4 at the size one GPU of the 8-GPU job runs it: K = 50 000, 12.5 M rows, ~590 M stored entries
+    (benchmarks/bow_csr.py's generator).  Far beyond what the oracle finishes, so the CSR pass
+    (DE/dme.py:113-123, DE/fdp.py:87-89) is checked against independent torch reductions on the
+    device: every (column, count) cell against a bincount taken in blocks, the row-total histogram
+    against a bincount of prefix-sum differences, the mean accumulators against an fp64 index_add_
+    (1e-11), the row count, and additivity - two half passes into one object give the same bits as
+    the whole.  The partitioned pass meets streams of hundreds of chunks and the full chunk pool only
+    at this size."""
+    from bayespy_amd import device
+    generate = _bow_generator()
+    K, N0 = 50_000, 12_500_000
+    rowptr, colidx, vals = generate(N0, K)
+    N, nnz = rowptr.numel() - 1, colidx.numel()
+    assert N >= N0 and nnz > 500_000_000
+    cs = torch.zeros(nnz + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(vals, 0, dtype=torch.int64, out=cs[1:])
+    totals = cs[rowptr[1:]] - cs[rowptr[:-1]]
+    del cs
+    max_count, max_total = int(vals.max()), int(totals.max())
+    st = device.DeviceStats(K, max_count, max_total)
+    st.add_csr(rowptr, colidx, vals, max_count=max_count, max_total=max_total)
+    info = st.check()
+    assert info["rows"] == N and info["max_count"] == max_count and info["max_total"] == max_total
+    nb = st.nbins
+    hist = st.hist.view(K, nb)
+    # (column, count) cells
+    want = torch.zeros(K * nb, dtype=torch.int64, device="cuda")
+    step = 1 << 26
+    for lo in range(0, nnz, step):
+        key = colidx[lo:lo + step].to(torch.int64) * nb + vals[lo:lo + step].to(torch.int64)
+        want += torch.bincount(key, minlength=K * nb)
+        del key
+    assert torch.equal(hist.reshape(-1), want)
+    del want
+    # row totals
+    assert torch.equal(st.histV[:st.tbins], torch.bincount(totals, minlength=st.tbins)[:st.tbins])
+    # mean accumulators: sum of x / (1 + n_row) per column
+    lens = rowptr[1:] - rowptr[:-1]
+    w = 1.0 / (1.0 + totals.to(torch.float64))
+    # (blocks of 2^18 rows summed on their own, then the blocks pairwise: a single running fp64 sum of
+    # 1e7 terms would itself be off by more than the bar)
+    parts = []
+    row_step = 1 << 18
+    for r0 in range(0, N, row_step):
+        r1 = min(N, r0 + row_step)
+        e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+        we = torch.repeat_interleave(w[r0:r1], lens[r0:r1], output_size=e1 - e0)
+        part = torch.zeros(K, dtype=torch.float64, device="cuda")
+        part.index_add_(0, colidx[e0:e1].to(torch.int64), we * vals[e0:e1].to(torch.float64))
+        parts.append(part)
+        del we
+    acc = torch.stack(parts).sum(dim=0)
+    del parts
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), acc.cpu().numpy(), rtol=1e-11, atol=0)
+    # two half passes add to the whole (integers bit for bit)
+    h = N // 2
+    eh = int(rowptr[h])
+    st2 = device.DeviceStats(K, max_count, max_total)
+    st2.add_csr(rowptr[:h + 1].contiguous(), colidx[:eh], vals[:eh], max_count=max_count, max_total=max_total)
+    st2.add_csr((rowptr[h:] - eh).contiguous(), colidx[eh:], vals[eh:], max_count=max_count, max_total=max_total)
+    assert st2.check()["rows"] == N
+    assert torch.equal(st2.hist, st.hist) and torch.equal(st2.histV, st.histV)
+    np.testing.assert_allclose(st2.init_acc.cpu().numpy(), st.init_acc.cpu().numpy(), rtol=1e-12, atol=0)
+
+
 def test_regression_callers_start_point_at_scale(oracle):
     """DirichletRegression/dirichletRegression.py:137-141 takes its baseline prior
     from findDirichletPriors(data, [1.0] * K, 50) - a start far from the optimum, which walks the
