@@ -116,7 +116,7 @@ inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan*
     p->off_bcount = o;   o = align256(o + 4 * MAXB);
     p->off_bpos = o;     o = align256(o + 4 * MAXB);
     p->off_images = o;   o = align256(o + (long long)(p->NB + p->W) * p->image_bytes);
-    p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL);
+    p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL + (long long)p->G3 * 4096 * 4LL);  // + the tile kernel's dump areas
     p->bytes = o;
     return true;
 }
@@ -489,6 +489,18 @@ __global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
 // (non-negative, non-decreasing, within nnz).  A rowptr that is not leaves everything to the row-wise
 // kernel: rows that overlap or run backwards have no place in a partition of the entries.
 // =====================================================================================================
+// -DDME_CSR3_TS: thread 0 of every workgroup adds the shader cycles (s_memtime) it spends in each phase
+// of the tile loop to the first words of the workspace (benchmarks/csr_phases.py reads them).
+#ifdef DME_CSR3_TS
+#define TS_DECL u64 ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 ts_last = __builtin_amdgcn_s_memtime();
+#define TS_MARK(i) { const u64 ts_now = __builtin_amdgcn_s_memtime(); ts_acc[i] += ts_now - ts_last; ts_last = ts_now; }
+#define TS_FLUSH(p) if (threadIdx.x == 0) { for (int i = 0; i < 8; ++i) atomicAdd((u64*)(p) + i, ts_acc[i]); }
+#else
+#define TS_DECL
+#define TS_MARK(i)
+#define TS_FLUSH(p)
+#endif
+
 constexpr int T3 = 512;               // threads of a tile workgroup
 constexpr int T3W = T3 / 64;
 constexpr int EPT = 8;                // entries per thread
@@ -499,6 +511,7 @@ constexpr u32 HUGE_V = 1u << 19;      // counts from here on: row totals are add
 struct TileArgs {
     PartArgs a;
     u32* flag;             // written by the check kernel: != 0 = malformed rowptr
+    u64* ts;               // phase time stamps (-DDME_CSR3_TS builds)
     long long* rstart;     // [G + 1] number of rows that start before E0 + g S; [G]: before rowptr[N]
     int G;
     long long chunks_per_wg;
@@ -549,24 +562,43 @@ struct TileLds {
     u32 F[TILE];          // window index + 1 of the row that starts at an entry position (0: none)
     u32 PX[TILE + 4];     // exclusive prefix sums of the tile's counts; from P4 on: the staged records
     u64 RT[RW];           // row totals of the window's rows
+    u32 RT32[RW];         // ... saturated to 32 bits (what the plain path reads)
     u32 cnt[MAXB];        // records of the tile per bucket (P2), zeroed again in P3
-    u32 off[MAXB + 1];    // the buckets' runs in the staging area
+    // per bucket {first staged position of its run, records that still fit the stream's open chunk,
+    // destination of the run's record 0 in that chunk, destination of record 0 in the chunks taken for
+    // this tile (their ids are consecutive)}: destination of record i = i < .y ? .z + i : .w + i
+    u32x4v prm[MAXB];
+    u32 staged;           // records of the tile in the staging area
+    unsigned char SB[TILE];  // bucket of every staged record
     u32 len[MAXB];        // records written to the bucket's stream so far
-    u32 lenold[MAXB];     // ... before this tile
     u32 cur[MAXB];        // id of the stream's last chunk
-    u32 curold[MAXB];
-    u32 newbase[MAXB];    // first of the chunk ids taken for this tile's run
-    u32 wsum[T3W], wmax[T3W], wrows[T3W];
+    u32 wsum[T3W], wrows[T3W];
+    u32 WR[T3W];          // window index + 1 of the row that holds the entry in front of wave w's first
     u32 straddle;         // window index + 1 of the row that runs over the tile's end
     u32 wg_next;          // chunk ids taken from the workgroup's range
     u32 huge;             // a count >= HUGE_V in the tile
-    u32 pad;
+    u32 cut;              // the tile ends here (relative): the first entry of the row that would run over its end
     long long tail_hi;    // where that row ends
     u64 head_extra, tail_extra;
     u64 stat[8];
 };
 
-__global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
+// An entry the plain path does not take: a count the record (>= 256) or the caller's histogram (>= nbins)
+// cannot hold, a row total a record cannot hold, a negative count, a column out of range.  Same rules as
+// the row-wise kernel's `process`.  Out of line: its registers and the division stay out of the tile loop.
+// Returns 1 for a bad entry (status[3]), 2 for a count beyond the caller's histogram (status[1]), else 0.
+__device__ __noinline__ int csr3_rare_entry(u64* hist, double* init_acc, long long nbins, long long K, u32 c,
+                                            u32 v, u64 total) {
+    if ((int)v < 0 || c >= (u32)K) return 1;
+    int r = 0;
+    if ((long long)v < nbins) atomicAdd(&hist[(long long)c * nbins + v], 1ULL);
+    else r = 2;  // reported, not counted; the mean accumulator still takes it
+    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
+    atomicAdd(&init_acc[c], __dmul_rn((double)v, w));
+    return r;
+}
+
+__global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const PartArgs& a = ta.a;
     if (*ta.flag != 0) return;  // malformed rowptr: the row-wise kernel takes the call
@@ -594,8 +626,10 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
         L.cur[tid] = 0xFFFFFFFFu;
     }
     if (tid < 8) L.stat[tid] = 0;
+    if (tid < T3W) L.WR[tid] = 0;
     if (tid == 0) {
         L.straddle = 0;
+        L.cut = 0xFFFFFFFFu;
         L.wg_next = 0;
         L.huge = 0;
         L.tail_hi = 0;
@@ -614,8 +648,9 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
 
     const u32 cmask = (1u << a.sh) - 1;
     const u32 vmax = a.nbins < (long long)VLIM ? (u32)a.nbins : VLIM;  // counts a record and hist hold
-    u32 maxv = 0;
-    u64 maxt = 0, bad = 0, big = 0, nrows = 0, over = 0, pool = 0;
+    // statistics of the pass: the two maxima in registers, the rare events straight to LDS (L.stat)
+    u32 maxv = 0, maxt32 = 0;
+    const long long jown_first = jown;
 
     // ---- loads of a tile: three row pointers and eight entries per thread -------------------------------
     auto load_window = [&](long long jb_, long long& q0, long long& q1, long long& qrw) {
@@ -663,7 +698,9 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
     load_entries(apos, nc, nv);
     __syncthreads();
 
+    TS_DECL
     while (true) {
+        TS_MARK(5)
         const long long Q0 = nq0, Q1 = nq1, QRW = nqrw;
         u32 c[EPT], v[EPT];
 #pragma unroll
@@ -672,29 +709,30 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
             v[i] = nv[i];
         }
         // ---- the tile: entries [apos, anext), rows [jown, jownN) ---------------------------------------
+        // First the tile as far as it could reach: TILE entries, the workgroup's end or the window's end.
+        // A row that starts inside it and runs over that end is left to the next tile whole (the tile is
+        // CUT at its first entry; agreed behind barrier B1): a row's entries then lie in one tile, and its
+        // total is a difference of two prefix sums.  Only a row that began before the tile (longer than a
+        // tile, or cut by the workgroup's range) needs what it holds outside, read again from memory.
         long long alim = apos + TILE;
         if (alim > Aend) alim = Aend;
         const bool exhausted = jb + RW < N && QRW < alim;  // the window's rows end before the entries do
-        const long long anext = exhausted ? QRW : alim;
-        const int n_ent = (int)(anext - apos);
-        const bool fin = anext >= E1;                      // the matrix' entries are done
+        const long long anext0 = exhausted ? QRW : alim;
         const int jrel = (int)(jown - jb);                 // 1: window row 0 began before the tile
         const bool vrow = jb + tid < N;
-        const bool owned = vrow && tid >= jrel && (exhausted || Q0 < anext || (last && fin));
-        // positions relative to the tile, clamped to [-1, n_ent + 1]
-        long long sl = Q0 - apos, tl = Q1 - apos;
-        const int s_rel = sl < 0 ? -1 : (sl > n_ent ? n_ent + 1 : (int)sl);
-        const int t_rel = tl < 0 ? -1 : (tl > n_ent ? n_ent + 1 : (int)tl);
-        const bool over_end = vrow && Q0 < anext && Q1 > anext;  // at most one row
-
+        const bool over_end = vrow && Q0 < anext0 && Q1 > anext0;  // at most one row
+        const bool cut_here = over_end && Q0 > apos;
+        const bool owned0 = vrow && tid >= jrel && !cut_here &&
+                            (exhausted || Q0 < anext0 || (last && anext0 >= E1));
         // ---- P1 ------------------------------------------------------------------------------------------
         u32 vp[EPT];
         u32 tsum = 0;
         bool hg = false;
         const int k0 = tid * EPT;
+        const int n_ent0 = (int)(anext0 - apos);
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            const bool in = k0 + i < n_ent;
+            const bool in = k0 + i < n_ent0;  // beyond a cut the sums are not read
             const int x = (int)v[i];
             u32 pv = in && x > 0 ? (u32)x : 0u;
             hg |= pv >= HUGE_V;
@@ -705,15 +743,18 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
         const u32 incl = dme_wave_incl_scan_u32(tsum);
         if (lane == 63) L.wsum[wave] = incl;
         {
-            const u64 ob = __ballot(owned);
+            const u64 ob = __ballot(owned0);
             if (lane == 0) L.wrows[wave] = (u32)__popcll(ob);
             if (__any(hg) && lane == 0) L.huge = 1;
         }
         if (over_end) {
             L.straddle = (u32)tid + 1;
             L.tail_hi = Q1;
+            if (cut_here) L.cut = (u32)(Q0 - apos);
         }
+        TS_MARK(0)
         __syncthreads();  // B1
+        TS_MARK(6)
 
         // ---- P2 ------------------------------------------------------------------------------------------
         u32 rows_owned = 0, wbase = 0;
@@ -723,8 +764,17 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
             rows_owned += r;
             wbase += w < wave ? x : 0u;
         }
-        const u32 strad = L.straddle;
+        const u32 strad = L.straddle, cutv = L.cut;
         const bool has_huge = L.huge != 0;
+        const bool is_cut = cutv != 0xFFFFFFFFu;
+        const long long anext = is_cut ? apos + (long long)cutv : anext0;
+        const int n_ent = (int)(anext - apos);
+        const bool tail = strad != 0 && !is_cut;           // a row that began at or before apos runs over the end
+        const bool owned = owned0;
+        // positions relative to the tile, clamped to [-1, n_ent + 1]
+        const long long sl = Q0 - apos, tl = Q1 - apos;
+        const int s_rel = sl < 0 ? -1 : (sl > n_ent ? n_ent + 1 : (int)sl);
+        const int t_rel = tl < 0 ? -1 : (tl > n_ent ? n_ent + 1 : (int)tl);
         const long long jownN = jown + rows_owned;
         const long long jbN = strad ? jb + (long long)strad - 1 : jownN;
         const bool cont = anext < Aend || (last && jownN < N);
@@ -740,14 +790,19 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
             if (tid == T3 - 1) L.PX[TILE] = tbase + tsum;
         }
         if (vrow && s_rel >= 0 && s_rel < n_ent) atomicMax(&L.F[s_rel], (u32)tid + 1);
-        bool ok[EPT];
-        u32 rank[EPT];
+        if (vrow && t_rel > s_rel && s_rel < n_ent) {
+            // this row holds the entry in front of a wave's first one (position 512 w - 1): that wave's
+            // entries start out in this row
+            for (int w = s_rel < 0 ? 1 : (s_rel >> 9) + 1; w < T3W && (w << 9) <= t_rel; ++w) L.WR[w] = (u32)tid + 1;
+        }
+        u32 okm = 0;  // bit i: entry i goes to the staging area
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const bool in = k0 + i < n_ent;
-            ok[i] = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
-            rank[i] = 0;
-            if (ok[i]) rank[i] = atomicAdd(&L.cnt[c[i] >> a.sh], 1u);
+            const bool ok = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
+            // its number in its bucket's run rides above the count (< 256) from here on
+            if (ok) v[i] |= atomicAdd(&L.cnt[c[i] >> a.sh], 1u) << VBITS;
+            okm |= ok ? 1u << i : 0u;
         }
         if (wave == 0 && jrel == 1) {  // window row 0 began before the tile: its entries in front of it
             const long long h0 = (long long)((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)Q0) |
@@ -755,44 +810,47 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
             const u64 x = wave_row_part(h0, apos);
             if (lane == 0) L.head_extra = x;
         }
-        if (wave == 1 && strad) {      // the row that runs over the tile's end: its entries behind it
+        if (wave == 1 && tail) {       // a row that began before the tile and runs over its end: its entries behind it
             const u64 x = wave_row_part(anext, L.tail_hi);
             if (lane == 0) L.tail_extra = x;
         }
+        TS_MARK(1)
         __syncthreads();  // B2
+        TS_MARK(6)
 
         // ---- P3 ------------------------------------------------------------------------------------------
-        if (wave == 0) {  // lane = bucket: the runs of the staging area, chunk ids for what they add
+        if (wave == T3W - 1) {  // lane = bucket: the runs of the staging area, chunk ids for what they add
             const u32 m = L.cnt[lane];
             const u32 inc = dme_wave_incl_scan_u32(m);
-            L.off[lane] = inc - m;
-            if (lane == 63) L.off[MAXB] = inc;
+            if (lane == 63) L.staged = inc;
             L.cnt[lane] = 0;
             const u32 lo = L.len[lane];
-            L.lenold[lane] = lo;
-            L.curold[lane] = L.cur[lane];
+            const u32 curold = L.cur[lane];
+            const u32 firstnew = (lo + CHUNK - 1) >> 10;            // chunks the stream has opened so far
+            u32 d0 = curold == 0xFFFFFFFFu ? 0xFFFFFC00u : (curold << 10) + (lo & (CHUNK - 1));
+            u32 d1 = 0xF0000000u;                                   // no chunk: beyond every pool, not stored
+            const u32 split = (firstnew << 10) - lo;                // 0 when the open chunk is full (or none is open)
             if (m > 0) {
-                const u32 firstnew = (lo + CHUNK - 1) >> 10;        // chunks the stream has opened so far
                 const u32 lastcn = (lo + m - 1) >> 10;              // chunk number of the run's last record
                 const u32 nnew = lastcn + 1 > firstnew ? lastcn + 1 - firstnew : 0u;
                 if (nnew) {
                     const long long id0 = cbase + (long long)atomicAdd(&L.wg_next, nnew);
-                    u32 nb32 = 0xFFFFFFFFu, lastid = 0xFFFFFFFFu;
+                    u32 lastid = 0xFFFFFFFFu;
                     if (id0 + nnew <= climit) {
-                        nb32 = (u32)id0;
+                        d1 = ((u32)id0 << 10) - split;
                         lastid = (u32)(id0 + nnew - 1);
                         for (u32 q = 0; q < nnew; ++q) {
                             a.chunk_bucket[id0 + q] = (unsigned char)lane;
                             a.chunk_fill[id0 + q] = (unsigned short)CHUNK;  // the stream's last one: corrected at the end
                         }
                     } else {
-                        pool++;  // cannot happen with a well-formed rowptr: the range is sized for S entries
+                        atomicAdd(&L.stat[6], 1ULL);  // cannot happen with a well-formed rowptr: the range is sized for S entries
                     }
-                    L.newbase[lane] = nb32;
                     L.cur[lane] = lastid;
                 }
                 L.len[lane] = lo + m;
             }
+            L.prm[lane] = u32x4v{inc - m, split, d0, d1};
         }
         if (vrow && (owned || (tid == 0 && jrel == 1))) {  // row totals (DE/dme.py:121 sum(row))
             u64 total;
@@ -801,7 +859,7 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
                 const int t0 = t_rel < 0 ? 0 : (t_rel > n_ent ? n_ent : t_rel);
                 total = (u64)(L.PX[t0] - L.PX[s0]);
                 if (tid == 0 && jrel == 1) total += L.head_extra;
-                if (strad == (u32)tid + 1) total += L.tail_extra;
+                if (tail && strad == (u32)tid + 1) total += L.tail_extra;
             } else {  // a count of 2^19 or more somewhere in the tile: this row's counts one by one, in 64 bits
                 total = 0;
                 for (long long q = Q0; q < Q1; ++q) {
@@ -810,122 +868,142 @@ __global__ __launch_bounds__(T3) void csr3_part_kernel(TileArgs ta) {
                 }
             }
             L.RT[tid] = total;
-            if (owned) {
-                nrows++;
-                if (total > 0) {
-                    maxt = total > maxt ? total : maxt;
-                    if (total < (u64)a.TB) atomicAdd(&tb[total], 1u);
-                    else if ((long long)total < a.tbins) atomicAdd(&a.histV[total], 1ULL);
-                    else over++;
+            L.RT32[tid] = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)total;
+            if (owned && total > 0) {
+                if (total < (u64)a.TB) {
+                    atomicAdd(&tb[total], 1u);
+                    maxt32 = (u32)total > maxt32 ? (u32)total : maxt32;
+                } else {
+                    atomicMax(&L.stat[5], total);
+                    if ((long long)total < a.tbins) atomicAdd(&a.histV[total], 1ULL);
+                    else atomicAdd(&L.stat[2], 1ULL);
                 }
             }
         }
-        u32 f[EPT];
-        u32 wexcl;
-        {
-            const u32x4v* fp = (const u32x4v*)&L.F[k0];
-            const u32x4v f0 = fp[0], f1 = fp[1];
-            u32x4v* fz = (u32x4v*)&L.F[k0];
-            fz[0] = u32x4v{0u, 0u, 0u, 0u};  // for the next tile (its rows write after two more barriers)
-            fz[1] = u32x4v{0u, 0u, 0u, 0u};
-            f[0] = f0.x;
-            f[1] = max(f[0], f0.y);
-            f[2] = max(f[1], f0.z);
-            f[3] = max(f[2], f0.w);
-            f[4] = max(f[3], f1.x);
-            f[5] = max(f[4], f1.y);
-            f[6] = max(f[5], f1.z);
-            f[7] = max(f[6], f1.w);
-            const u32 winc = wave_incl_scan_max_u32(f[7]);
-            wexcl = wave_shr1_u32(winc);
-            if (lane == 63) L.wmax[wave] = winc;
-        }
+        TS_MARK(2)
         __syncthreads();  // B3
+        TS_MARK(6)
 
         // ---- P4 ------------------------------------------------------------------------------------------
         if (tid == 0) {
             L.straddle = 0;
+            L.cut = 0xFFFFFFFFu;
             L.huge = 0;
         }
+        {
+            // every entry's row: the largest F at or before it - a running maximum inside the thread, a DPP
+            // max-scan over the wave's threads, and the row the wave starts out in
+            u32 f[EPT];
+            {
+                const u32x4v* fp = (const u32x4v*)&L.F[k0];
+                const u32x4v f0 = fp[0], f1 = fp[1];
+                u32x4v* fz = (u32x4v*)&L.F[k0];
+                fz[0] = u32x4v{0u, 0u, 0u, 0u};  // for the next tile (its rows write behind two more barriers)
+                fz[1] = u32x4v{0u, 0u, 0u, 0u};
+                f[0] = f0.x;
+                f[1] = max(f[0], f0.y);
+                f[2] = max(f[1], f0.z);
+                f[3] = max(f[2], f0.w);
+                f[4] = max(f[3], f1.x);
+                f[5] = max(f[4], f1.y);
+                f[6] = max(f[5], f1.z);
+                f[7] = max(f[6], f1.w);
+            }
+            const u32 wexcl = max(wave_shr1_u32(wave_incl_scan_max_u32(f[7])), L.WR[wave]);
+            // the plain path, eight entries side by side: row total and run offset from LDS, one wait, the
+            // records to the staging area; entries it cannot take are only marked
+            u32 tot[EPT], ofs[EPT];
 #pragma unroll
-        for (int w = 0; w < T3W; ++w) {
-            const u32 x = L.wmax[w];
-            wexcl = max(wexcl, w < wave ? x : 0u);
-        }
+            for (int i = 0; i < EPT; ++i) {
+                u32 ri = max(f[i], wexcl);
+                ri = ri > 0 ? ri - 1 : 0u;  // entries in front of the first row start: window row 0
+                f[i] = ri;
+                tot[i] = L.RT32[ri];
+                ofs[i] = L.prm[(c[i] >> a.sh) & (MAXB - 1)].x;
+            }
+            bool rare = false;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const bool in = k0 + i < n_ent;
-            if (!in || v[i] == 0) continue;
-            u32 ri = max(f[i], wexcl);
-            ri = ri > 0 ? ri - 1 : 0u;  // entries in front of the first row start: window row 0
-            const u64 total = L.RT[ri];
-            if (ok[i]) {
-                maxv = v[i] > maxv ? v[i] : maxv;
-                u32 rec = 0;  // a record with count 0 is skipped by the bucket pass
-                if (total < (u64)TLIM) {
-                    rec = (c[i] & cmask) | (v[i] << COLBITS) | ((u32)total << (COLBITS + VBITS));
-                } else {      // a record cannot hold the row total
-                    atomicAdd(&a.hist[(long long)c[i] * a.nbins + v[i]], 1ULL);
-                    const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
-                    atomicAdd(&a.init_acc[c[i]], __dmul_rn((double)v[i], w));
+            for (int i = 0; i < EPT; ++i) {
+                const bool in = k0 + i < n_ent;
+                const bool ok = (okm >> i) & 1u;
+                const bool fits = tot[i] < TLIM;
+                const u32 cnt8 = v[i] & (VLIM - 1), rank = v[i] >> VBITS;  // of an entry with `ok`
+                const u32 rec = fits ? (c[i] & cmask) | (cnt8 << COLBITS) | (tot[i] << (COLBITS + VBITS)) : 0u;
+                if (ok) {
+                    L.PX[ofs[i] + rank] = rec;  // a record with count 0 is skipped by the bucket pass
+                    L.SB[ofs[i] + rank] = (unsigned char)(c[i] >> a.sh);
+                    maxv = cnt8 > maxv ? cnt8 : maxv;
                 }
-                L.PX[L.off[c[i] >> a.sh] + rank[i]] = rec;
-            } else if ((int)v[i] < 0 || c[i] >= (u32)a.K) {
-                bad++;
-            } else {  // a count the record (>= 256) or the caller's histogram (>= nbins) cannot hold
-                maxv = v[i] > maxv ? v[i] : maxv;
-                if ((long long)v[i] < a.nbins) atomicAdd(&a.hist[(long long)c[i] * a.nbins + v[i]], 1ULL);
-                else big++;  // reported, not counted; the mean accumulator still takes it
-                const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
-                atomicAdd(&a.init_acc[c[i]], __dmul_rn((double)v[i], w));
+                rare |= in && v[i] != 0 && !(ok && fits);
+            }
+            if (__any(rare)) {
+#pragma unroll 1
+                for (int i = 0; i < EPT; ++i) {
+                    const bool in = k0 + i < n_ent;
+                    const bool ok = (okm >> i) & 1u;
+                    if (!in || v[i] == 0 || (ok && tot[i] < TLIM)) continue;
+                    const u32 cnt = ok ? v[i] & (VLIM - 1) : v[i];
+                    if ((int)cnt > 0 && c[i] < (u32)a.K) maxv = cnt > maxv ? cnt : maxv;
+                    const int r = csr3_rare_entry(a.hist, a.init_acc, a.nbins, a.K, c[i], cnt, L.RT[f[i]]);
+                    if (r == 1) atomicAdd(&L.stat[3], 1ULL);
+                    if (r == 2) atomicAdd(&L.stat[1], 1ULL);
+                }
             }
         }
+        TS_MARK(3)
         __syncthreads();  // B4
+        TS_MARK(6)
 
         // ---- P5: the runs leave for the buckets' streams -----------------------------------------------------
-        for (int b = wave; b < a.NB; b += T3W) {
-            const u32 o = L.off[b], m = L.off[b + 1] - o;
-            if (m == 0) continue;
-            const u32 lo = L.lenold[b], curold = L.curold[b], nbase = L.newbase[b];
-            const u32 firstnew = (lo + CHUNK - 1) >> 10;
-            for (u32 i = lane; i < m; i += 64) {
-                const u32 rec = L.PX[o + i];
-                const u32 p = lo + i;
-                const u32 cn = p >> 10;
-                u32 id;
-                if (cn < firstnew) id = curold;
-                else id = nbase == 0xFFFFFFFFu ? nbase : nbase + (cn - firstnew);
-                if (id != 0xFFFFFFFFu) a.chunks[(long long)id * CHUNK + (p & (CHUNK - 1))] = rec;
+        {
+            // thread t takes the staged records t, t + 512, ...: neighbours in a run are neighbours in the
+            // bucket's stream, so a wave's store covers a few contiguous pieces
+            const u32 staged = L.staged;
+            const u32 dlimit = (u32)(a.max_chunks << 10);
+            const u32 dump = dlimit + (u32)g * TILE;
+            if (tid < T3W) L.WR[tid] = 0;  // read in P4, written again in the next tile's P2
+            u32 t2 = (u32)tid;  // opaque: keeps the eight positions and dump slots from being held (and spilled) across the loop
+            asm volatile("" : "+v"(t2));
+            u32 rec[EPT], bk[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const u32 pos = (u32)(k * T3) + t2;
+                rec[k] = L.PX[pos];
+                bk[k] = L.SB[pos];
+            }
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const u32 pos = (u32)(k * T3) + t2;
+                const u32x4v pr = L.prm[bk[k] & (MAXB - 1)];
+                const u32 i = pos - pr.x;
+                u32 dst = i < pr.y ? pr.z + i : pr.w + i;
+                // always eight stores (slots nobody staged go to the workgroup's dump area behind the pool):
+                // the wait for the next tile's loads, issued before them, can then count them out
+                // (s_waitcnt vmcnt(8)) instead of waiting for their acknowledgements too
+                if (!(pos < staged && dst < dlimit)) dst = dump + pos;
+                a.chunks[dst] = rec[k];
             }
         }
+        TS_MARK(4)
+        jown = jownN;
         if (!cont) break;
         apos = anext;
         jb = jbN;
-        jown = jownN;
     }
 
+    TS_FLUSH(ta.ts)
     // ---- the streams' last chunks, the statistics of the pass ----------------------------------------------
     __syncthreads();
     if (tid < a.NB) {
         const u32 n = L.len[tid], id = L.cur[tid];
         if (n > 0 && (n & (CHUNK - 1)) && id != 0xFFFFFFFFu) a.chunk_fill[id] = (unsigned short)(n & (CHUNK - 1));
     }
-    nrows = dme_wave_sum_u64(nrows);
-    bad = dme_wave_sum_u64(bad);
-    big = dme_wave_sum_u64(big);
-    over = dme_wave_sum_u64(over);
-    pool = dme_wave_sum_u64(pool);
-    const u32 mv = dme_wave_max_u32(maxv);
-    maxt = dme_wave_max_u64(maxt);
+    const u32 mv = dme_wave_max_u32(maxv), mt = dme_wave_max_u32(maxt32);
     if (lane == 0) {
-        if (nrows) atomicAdd(&L.stat[0], nrows);
-        if (big) atomicAdd(&L.stat[1], big);
-        if (over) atomicAdd(&L.stat[2], over);
-        if (bad) atomicAdd(&L.stat[3], bad);
         if (mv) atomicMax(&L.stat[4], (u64)mv);
-        if (maxt) atomicMax(&L.stat[5], maxt);
-        if (pool) atomicAdd(&L.stat[6], pool);
+        if (mt) atomicMax(&L.stat[5], (u64)mt);
     }
+    if (tid == 0 && jown > jown_first) atomicAdd(&L.stat[0], (u64)(jown - jown_first));  // rows this workgroup owned
     __syncthreads();
     for (int i = tid; i < a.TB; i += T3) {
         const u32 cn = tb[i];
@@ -1248,6 +1326,10 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     DME_HIP_CHECK(hipMemsetAsync(ws + p.off_flag, 0, (size_t)(p.off_rstart - p.off_flag) + 8 * ((size_t)p.G3 + 1), s));
     TileArgs ta{};
     ta.flag = (u32*)(ws + p.off_flag);
+    ta.ts = (u64*)(ws + p.off_head);
+#ifdef DME_CSR3_TS
+    DME_HIP_CHECK(hipMemsetAsync(ws + p.off_head, 0, 256, s));
+#endif
     ta.rstart = (long long*)(ws + p.off_rstart);
     ta.G = p.G3;
     ta.chunks_per_wg = p.chunks_per_wg3;
