@@ -563,7 +563,7 @@ struct TileLds {
     u32 PX[TILE + 4];     // exclusive prefix sums of the tile's counts; from P4 on: the staged records
     u64 RT[RW];           // row totals of the window's rows
     u32 RT32[RW];         // ... saturated to 32 bits (what the plain path reads)
-    u32 cnt[MAXB];        // records of the tile per bucket (P2), zeroed again in P3
+    u32 cnt[MAXB + 4];    // records of the tile per bucket (P2), zeroed again in P3; [MAXB]: sink
     // per bucket {first staged position of its run, records that still fit the stream's open chunk,
     // destination of the run's record 0 in that chunk, destination of record 0 in the chunks taken for
     // this tile (their ids are consecutive)}: destination of record i = i < .y ? .z + i : .w + i
@@ -578,7 +578,6 @@ struct TileLds {
     u32 wg_next;          // chunk ids taken from the workgroup's range
     u32 huge;             // a count >= HUGE_V in the tile
     u32 cut;              // the tile ends here (relative): the first entry of the row that would run over its end
-    long long tail_hi;    // where that row ends
     u64 head_extra, tail_extra;
     u64 stat[8];
 };
@@ -598,6 +597,8 @@ __device__ __noinline__ int csr3_rare_entry(u64* hist, double* init_acc, long lo
     return r;
 }
 
+__device__ __forceinline__ u32 uni(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+
 __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const PartArgs& a = ta.a;
@@ -608,13 +609,16 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = ta.G, g = blockIdx.x;
     const long long N = a.N;
-    const long long E0 = a.rowptr[0], E1 = a.rowptr[N];
-    long long S = (E1 - E0 + G - 1) / G;
+    // Row pointers are below 2^32 on this path (nnz < 2^32 and the check kernel has seen every pointer inside
+    // [0, nnz]): their low words are read, and the tile loop's positions are 32-bit scalars.
+    const u32* rp = (const u32*)a.rowptr;
+    const u32 E0 = rp[0], E1 = rp[2 * N];
+    u32 S = (u32)(((u64)(E1 - E0) + (u64)G - 1) / (u64)G);
     if (S < 1) S = 1;
-    long long A = E0 + (long long)g * S;
-    if (A > E1) A = E1;
-    long long Aend = A + S;
-    if (Aend > E1) Aend = E1;
+    const u64 A64 = (u64)E0 + (u64)g * S;
+    const u32 A = A64 > (u64)E1 ? E1 : (u32)A64;
+    const u64 Ae64 = (u64)A + S;
+    const u32 Aend = Ae64 > (u64)E1 ? E1 : (u32)Ae64;
     const bool last = g == G - 1;
     if (A >= E1 && !last) return;  // nothing of the matrix falls to this workgroup
 
@@ -632,7 +636,6 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         L.cut = 0xFFFFFFFFu;
         L.wg_next = 0;
         L.huge = 0;
-        L.tail_hi = 0;
         L.head_extra = 0;
         L.tail_extra = 0;
     }
@@ -643,8 +646,8 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     long long jown = A >= E1 ? ta.rstart[G] : ta.rstart[g];  // first row this workgroup owns
     if (jown > N) jown = N;
     long long jb = jown;                                       // first row of the window
-    if (A < E1 && jown >= 1 && a.rowptr[jown] > A) jb = jown - 1;  // the row that holds entry A began earlier
-    long long apos = A;
+    if (A < E1 && jown >= 1 && rp[2 * jown] > A) jb = jown - 1;  // the row that holds entry A began earlier
+    u32 apos = A;
 
     const u32 cmask = (1u << a.sh) - 1;
     const u32 vmax = a.nbins < (long long)VLIM ? (u32)a.nbins : VLIM;  // counts a record and hist hold
@@ -653,46 +656,49 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     const long long jown_first = jown;
 
     // ---- loads of a tile: three row pointers and eight entries per thread -------------------------------
-    auto load_window = [&](long long jb_, long long& q0, long long& q1, long long& qrw) {
-        long long j0 = jb_ + tid, j1 = j0 + 1, jr = jb_ + RW;
-        if (j0 > N) j0 = N;
-        if (j1 > N) j1 = N;
-        if (jr > N) jr = N;
-        q0 = a.rowptr[j0];
-        q1 = a.rowptr[j1];
-        qrw = a.rowptr[jr];
+    auto load_window = [&](long long jb_, u32& q0, u32& q1, u32& qrw) {
+        const long long rem = N - jb_;  // rows from the window's first one to the matrix' end (>= 0)
+        const u32 rem32 = rem > (long long)RW ? (u32)RW : (u32)rem;
+        const u32* base = rp + 2 * jb_;
+        const u32 j0 = (u32)tid < rem32 ? (u32)tid : rem32, j1 = (u32)tid + 1 < rem32 ? (u32)tid + 1 : rem32;
+        q0 = base[2 * j0];
+        q1 = base[2 * j1];
+        qrw = base[2 * rem32];
     };
-    auto load_entries = [&](long long ap, u32 (&c)[EPT], u32 (&v)[EPT]) {
-        const long long e = ap + (long long)tid * EPT;
+    auto load_entries = [&](u32 ap, u32 (&c)[EPT], u32 (&v)[EPT]) {
+        const u32 left = E1 - ap;  // entries from the tile's first one to the matrix' end
+        const int* cb = a.colidx + ap;
+        const int* vb = a.vals + ap;
 #pragma unroll
         for (int h = 0; h < EPT / 4; ++h) {
-            const long long eh = e + 4 * h;
-            if (eh + 3 < E1) {
-                const u32x4v cc = __builtin_nontemporal_load((const u32x4v_u*)(a.colidx + eh));
-                const u32x4v vv = __builtin_nontemporal_load((const u32x4v_u*)(a.vals + eh));
+            const u32 eh = (u32)tid * EPT + 4 * h;
+            if (eh + 3 < left) {
+                const u32x4v cc = __builtin_nontemporal_load((const u32x4v_u*)(cb + eh));
+                const u32x4v vv = __builtin_nontemporal_load((const u32x4v_u*)(vb + eh));
                 c[4 * h] = cc.x; c[4 * h + 1] = cc.y; c[4 * h + 2] = cc.z; c[4 * h + 3] = cc.w;
                 v[4 * h] = vv.x; v[4 * h + 1] = vv.y; v[4 * h + 2] = vv.z; v[4 * h + 3] = vv.w;
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool in = eh + i < E1;
-                    c[4 * h + i] = in ? (u32)a.colidx[eh + i] : 0u;
-                    v[4 * h + i] = in ? (u32)a.vals[eh + i] : 0u;
+                    const bool in = eh + i < left;
+                    c[4 * h + i] = in ? (u32)cb[eh + i] : 0u;
+                    v[4 * h + i] = in ? (u32)vb[eh + i] : 0u;
                 }
             }
         }
     };
     // sum of the positive counts in [lo, hi) by one wave (what a row holds outside the tile)
-    auto wave_row_part = [&](long long lo, long long hi) -> u64 {
+    auto wave_row_part = [&](u32 lo, u32 hi) -> u64 {
         u64 s = 0;
-        for (long long q = lo + lane; q < hi; q += 64) {
-            const int x = a.vals[q];
+        const u64 n = hi > lo ? (u64)(hi - lo) : 0;
+        for (u64 o = (u64)lane; o < n; o += 64) {
+            const int x = a.vals[(u64)lo + o];
             s += (u64)(x > 0 ? x : 0);
         }
         return dme_wave_sum_u64(s);
     };
 
-    long long nq0, nq1, nqrw;
+    u32 nq0, nq1, nqrw;
     u32 nc[EPT], nv[EPT];
     load_window(jb, nq0, nq1, nqrw);
     load_entries(apos, nc, nv);
@@ -701,38 +707,44 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     TS_DECL
     while (true) {
         TS_MARK(5)
-        const long long Q0 = nq0, Q1 = nq1, QRW = nqrw;
+        const u32 q0 = nq0, q1 = nq1, qrw = uni(nqrw);
         u32 c[EPT], v[EPT];
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             c[i] = nc[i];
             v[i] = nv[i];
         }
-        // ---- the tile: entries [apos, anext), rows [jown, jownN) ---------------------------------------
+        // ---- the tile: entries [apos, apos + n_ent), rows [jown, jownN) -------------------------------
         // First the tile as far as it could reach: TILE entries, the workgroup's end or the window's end.
         // A row that starts inside it and runs over that end is left to the next tile whole (the tile is
         // CUT at its first entry; agreed behind barrier B1): a row's entries then lie in one tile, and its
         // total is a difference of two prefix sums.  Only a row that began before the tile (longer than a
         // tile, or cut by the workgroup's range) needs what it holds outside, read again from memory.
-        long long alim = apos + TILE;
-        if (alim > Aend) alim = Aend;
-        const bool exhausted = jb + RW < N && QRW < alim;  // the window's rows end before the entries do
-        const long long anext0 = exhausted ? QRW : alim;
-        const int jrel = (int)(jown - jb);                 // 1: window row 0 began before the tile
-        const bool vrow = jb + tid < N;
-        const bool over_end = vrow && Q0 < anext0 && Q1 > anext0;  // at most one row
-        const bool cut_here = over_end && Q0 > apos;
-        const bool owned0 = vrow && tid >= jrel && !cut_here &&
-                            (exhausted || Q0 < anext0 || (last && anext0 >= E1));
+        const u32 left = Aend - apos;                       // entries left of the workgroup's range
+        const u32 lim = left < (u32)TILE ? left : (u32)TILE;
+        const long long rows_left = N - jb;
+        const u32 wrows = rows_left > (long long)RW ? (u32)RW : (u32)rows_left;  // rows the window holds
+        const u32 qrw_rel = qrw - apos;                     // the window's end is never in front of the tile
+        const bool exhausted = rows_left > (long long)RW && qrw_rel < lim;  // its rows end before the entries do
+        const int n0 = (int)(exhausted ? qrw_rel : lim);
+        const int jrel = (int)(jown - jb);                  // 1: window row 0 began before the tile
+        const bool vrow = (u32)tid < wrows;
+        // the row's first entry and its end relative to the tile, clamped to [-1, TILE + 1]
+        const long long sl = (long long)q0 - (long long)apos, tl = (long long)q1 - (long long)apos;
+        const int s0 = sl < 0 ? -1 : (sl > TILE ? TILE + 1 : (int)sl);
+        const int t0 = tl < 0 ? -1 : (tl > TILE ? TILE + 1 : (int)tl);
+        const bool over_end = vrow && s0 < n0 && t0 > n0;  // at most one row
+        const bool cut_here = over_end && s0 > 0;
+        const bool owned = vrow && tid >= jrel && !cut_here && (exhausted || s0 < n0 || (last && apos + (u32)n0 >= E1));
+
         // ---- P1 ------------------------------------------------------------------------------------------
         u32 vp[EPT];
         u32 tsum = 0;
         bool hg = false;
         const int k0 = tid * EPT;
-        const int n_ent0 = (int)(anext0 - apos);
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            const bool in = k0 + i < n_ent0;  // beyond a cut the sums are not read
+            const bool in = k0 + i < n0;  // beyond a cut the sums are not read
             const int x = (int)v[i];
             u32 pv = in && x > 0 ? (u32)x : 0u;
             hg |= pv >= HUGE_V;
@@ -743,14 +755,13 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         const u32 incl = dme_wave_incl_scan_u32(tsum);
         if (lane == 63) L.wsum[wave] = incl;
         {
-            const u64 ob = __ballot(owned0);
+            const u64 ob = __ballot(owned);
             if (lane == 0) L.wrows[wave] = (u32)__popcll(ob);
             if (__any(hg) && lane == 0) L.huge = 1;
         }
         if (over_end) {
             L.straddle = (u32)tid + 1;
-            L.tail_hi = Q1;
-            if (cut_here) L.cut = (u32)(Q0 - apos);
+            if (cut_here) L.cut = (u32)s0;
         }
         TS_MARK(0)
         __syncthreads();  // B1
@@ -758,23 +769,24 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
 
         // ---- P2 ------------------------------------------------------------------------------------------
         u32 rows_owned = 0, wbase = 0;
+        {
+            const u32x4v r0 = *(const u32x4v*)&L.wrows[0], r1 = *(const u32x4v*)&L.wrows[4];
+            const u32x4v x0 = *(const u32x4v*)&L.wsum[0], x1 = *(const u32x4v*)&L.wsum[4];
+            const u32 r[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const u32 x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-        for (int w = 0; w < T3W; ++w) {
-            const u32 r = L.wrows[w], x = L.wsum[w];
-            rows_owned += r;
-            wbase += w < wave ? x : 0u;
+            for (int w = 0; w < T3W; ++w) {
+                rows_owned += uni(r[w]);
+                wbase += w < wave ? uni(x[w]) : 0u;
+            }
         }
-        const u32 strad = L.straddle, cutv = L.cut;
-        const bool has_huge = L.huge != 0;
+        const u32 strad = uni(L.straddle), cutv = uni(L.cut);
+        const bool has_huge = uni(L.huge) != 0;
         const bool is_cut = cutv != 0xFFFFFFFFu;
-        const long long anext = is_cut ? apos + (long long)cutv : anext0;
-        const int n_ent = (int)(anext - apos);
+        const int n_ent = is_cut ? (int)cutv : n0;
+        const u32 anext = apos + (u32)n_ent;
         const bool tail = strad != 0 && !is_cut;           // a row that began at or before apos runs over the end
-        const bool owned = owned0;
-        // positions relative to the tile, clamped to [-1, n_ent + 1]
-        const long long sl = Q0 - apos, tl = Q1 - apos;
-        const int s_rel = sl < 0 ? -1 : (sl > n_ent ? n_ent + 1 : (int)sl);
-        const int t_rel = tl < 0 ? -1 : (tl > n_ent ? n_ent + 1 : (int)tl);
+        const int s_rel = s0 > n_ent ? n_ent + 1 : s0, t_rel = t0 > n_ent ? n_ent + 1 : t0;
         const long long jownN = jown + rows_owned;
         const long long jbN = strad ? jb + (long long)strad - 1 : jownN;
         const bool cont = anext < Aend || (last && jownN < N);
@@ -796,22 +808,27 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
             for (int w = s_rel < 0 ? 1 : (s_rel >> 9) + 1; w < T3W && (w << 9) <= t_rel; ++w) L.WR[w] = (u32)tid + 1;
         }
         u32 okm = 0;  // bit i: entry i goes to the staging area
+        {
+            // eight returning adds side by side, one wait (entries that are not staged add to a sink word:
+            // a branch around each add made every one of them wait for its own result)
+            u32 rk[EPT];
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-            const bool in = k0 + i < n_ent;
-            const bool ok = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
+            for (int i = 0; i < EPT; ++i) {
+                const bool in = k0 + i < n_ent;
+                const bool ok = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
+                okm |= ok ? 1u << i : 0u;
+                rk[i] = atomicAdd(&L.cnt[ok ? c[i] >> a.sh : (u32)MAXB], 1u);
+            }
             // its number in its bucket's run rides above the count (< 256) from here on
-            if (ok) v[i] |= atomicAdd(&L.cnt[c[i] >> a.sh], 1u) << VBITS;
-            okm |= ok ? 1u << i : 0u;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) v[i] |= (okm >> i) & 1u ? rk[i] << VBITS : 0u;
         }
         if (wave == 0 && jrel == 1) {  // window row 0 began before the tile: its entries in front of it
-            const long long h0 = (long long)((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)Q0) |
-                                             ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)((u64)Q0 >> 32)) << 32));
-            const u64 x = wave_row_part(h0, apos);
+            const u64 x = wave_row_part(rp[2 * jb], apos);
             if (lane == 0) L.head_extra = x;
         }
         if (wave == 1 && tail) {       // a row that began before the tile and runs over its end: its entries behind it
-            const u64 x = wave_row_part(anext, L.tail_hi);
+            const u64 x = wave_row_part(anext, rp[2 * (jb + (long long)strad)]);
             if (lane == 0) L.tail_extra = x;
         }
         TS_MARK(1)
@@ -855,14 +872,15 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         if (vrow && (owned || (tid == 0 && jrel == 1))) {  // row totals (DE/dme.py:121 sum(row))
             u64 total;
             if (!has_huge) {
-                const int s0 = s_rel < 0 ? 0 : (s_rel > n_ent ? n_ent : s_rel);
-                const int t0 = t_rel < 0 ? 0 : (t_rel > n_ent ? n_ent : t_rel);
-                total = (u64)(L.PX[t0] - L.PX[s0]);
+                const int sa = s_rel < 0 ? 0 : (s_rel > n_ent ? n_ent : s_rel);
+                const int ta_ = t_rel < 0 ? 0 : (t_rel > n_ent ? n_ent : t_rel);
+                total = (u64)(L.PX[ta_] - L.PX[sa]);
                 if (tid == 0 && jrel == 1) total += L.head_extra;
                 if (tail && strad == (u32)tid + 1) total += L.tail_extra;
             } else {  // a count of 2^19 or more somewhere in the tile: this row's counts one by one, in 64 bits
                 total = 0;
-                for (long long q = Q0; q < Q1; ++q) {
+                const u32 lo = rp[2 * (jb + tid)], hi = rp[2 * (jb + tid + 1)];
+                for (u64 q = lo; q < (u64)hi; ++q) {
                     const int x = a.vals[q];
                     total += (u64)(x > 0 ? x : 0);
                 }
@@ -909,7 +927,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                 f[6] = max(f[5], f1.z);
                 f[7] = max(f[6], f1.w);
             }
-            const u32 wexcl = max(wave_shr1_u32(wave_incl_scan_max_u32(f[7])), L.WR[wave]);
+            const u32 wexcl = max(wave_shr1_u32(wave_incl_scan_max_u32(f[7])), uni(L.WR[wave]));
             // the plain path, eight entries side by side: row total and run offset from LDS, one wait, the
             // records to the staging area; entries it cannot take are only marked
             u32 tot[EPT], ofs[EPT];
@@ -958,7 +976,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         {
             // thread t takes the staged records t, t + 512, ...: neighbours in a run are neighbours in the
             // bucket's stream, so a wave's store covers a few contiguous pieces
-            const u32 staged = L.staged;
+            const u32 staged = uni(L.staged);
             const u32 dlimit = (u32)(a.max_chunks << 10);
             const u32 dump = dlimit + (u32)g * TILE;
             if (tid < T3W) L.WR[tid] = 0;  // read in P4, written again in the next tile's P2
@@ -979,7 +997,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                 u32 dst = i < pr.y ? pr.z + i : pr.w + i;
                 // always eight stores (slots nobody staged go to the workgroup's dump area behind the pool):
                 // the wait for the next tile's loads, issued before them, can then count them out
-                // (s_waitcnt vmcnt(8)) instead of waiting for their acknowledgements too
+                // instead of waiting for their acknowledgements too
                 if (!(pos < staged && dst < dlimit)) dst = dump + pos;
                 a.chunks[dst] = rec[k];
             }
