@@ -1120,6 +1120,20 @@ struct BucketArgs {
 
 __device__ __forceinline__ u32 piece_chunks(u32 total, int W) { return (total + (u32)W - 1) / (u32)W; }
 
+// Frequent columns.  Word-frequency data puts a few columns in most rows (the three most frequent words
+// of BASELINE configs[3] stand in 90-100 % of the documents): half the records of such a column's bucket
+// carry the same column, and LDS atomics on one address take the lanes one after the other (2 cycles a
+// lane for ds_add_u32, 3 for ds_add_f64: benchmarks/micro/lds_atomics.hip) - the pieces of those buckets
+// ran twice as long as the rest (1.75 ms for the shard against 0.85 ms for data without frequent words).
+// Every run therefore looks at its first chunk, takes the HOT most frequent columns of it, and keeps them
+// out of the shared cells: their mean accumulators are registers of every thread (summed over the
+// workgroup at the end of the run), their counts go to a table of their own with HC copies of every bin,
+// the lane's copy chosen by its number.  Which columns are picked changes the speed only.
+constexpr int HOT = 2;   // frequent columns per run
+constexpr int HC = 8;    // copies of a frequent column's bins
+constexpr int HOT_MIN = 16;  // occurrences in the first chunk that make a column frequent
+constexpr int HOT_LDS_BYTES = HOT * (int)VLIM * HC * 4 + 64;
+
 __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
     extern __shared__ u64 lds64[];
     const int CB = 1 << a.sh;
@@ -1133,11 +1147,12 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
     u32* ocnt = okey + OVF;              // [OVF]
     // 1 / (1 + n) for row totals below WTAB (DE/fdp.py:88 weightForMean), behind the image: the fp64
     // division was a third of the pass's vector instructions
-    const double* wtab = (const double*)(ocnt + OVF);
-    for (int n = threadIdx.x; n < WTAB; n += BBLOCK)
-        ((double*)wtab)[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
+    double* wtab = (double*)(ocnt + OVF);
+    u32* hh = (u32*)(wtab + WTAB);       // [HOT][VLIM][HC] bins of the run's frequent columns
+    u32* top = hh + HOT * VLIM * HC;     // [HOT] count << 10 | column of the first chunk's most frequent columns
+    for (int n = threadIdx.x; n < WTAB; n += BBLOCK) wtab[n] = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n));
     const u32 acmask = (u32)a.AC - 1;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const u32 total = a.bstart[a.NB];
     const u32 piece = piece_chunks(total, a.W);
     u32 pos = piece * blockIdx.x;
@@ -1148,14 +1163,55 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
     while (a.bstart[b + 1] <= pos) ++b;  // NB <= 64
     const int cells = CB * a.BL;
     const u32 cmask = (1u << COLBITS) - 1;
+    // one (column, count) cell with `n` rows into the image: a bin, or the overflow table
+    auto add_cell = [&](u32 cl, u32 v, u32 n, long long kbase) {
+        if (v <= (u32)a.BL) {
+            atomicAdd(&h[(v - 1) * CB + cl], n);  // bin-major: bank = column
+            return;
+        }
+        const u32 key = ((cl << VBITS) | v) + 1u;
+        u32 slot = (key * 2654435761u) >> (32 - 11);  // OVF = 2^11
+        bool placed = false;
+        for (int probe = 0; probe < 16 && !placed; ++probe) {
+            const u32 old = atomicCAS(&okey[slot], 0u, key);
+            if (old == 0u || old == key) {
+                atomicAdd(&ocnt[slot], n);
+                placed = true;
+            }
+            slot = (slot + 1) & (OVF - 1);
+        }
+        if (!placed) atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], (u64)n);  // table crowded
+    };
     while (pos < end) {
         u32 seg_end = a.bstart[b + 1];
         if (seg_end > end) seg_end = end;
         if (seg_end > pos) {
             for (int i = tid; i < cells + 2 * OVF; i += BBLOCK) h[i] = 0;  // bins and overflow table
             for (int i = tid; i < a.AC * CB; i += BBLOCK) acc[i] = 0.0;
+            for (int i = tid; i < HOT * (int)VLIM * HC + HOT; i += BBLOCK) hh[i] = 0;  // and top[]
             __syncthreads();
             const long long kbase = (long long)b << a.sh;
+            // ---- the run's frequent columns: the first chunk counted by column in the first bin row ----------
+            u32 hot0 = 0xFFFFFFFFu, hot1 = 0xFFFFFFFFu;
+            {
+                const u32 se = a.sorted[pos];
+                const u32 rec = (u32)tid <= (se >> IDBITS) ? a.chunks[(long long)(se & ((1u << IDBITS) - 1)) * CHUNK + tid] : 0u;
+                if ((rec >> COLBITS) & (VLIM - 1)) atomicAdd(&h[rec & cmask], 1u);
+                __syncthreads();
+                const u32 key = tid < CB ? (h[tid] << COLBITS) | (u32)tid : 0u;
+                const u32 m0 = dme_wave_max_u32(key);
+                if (lane == 0 && m0) atomicMax(&top[0], m0);
+                __syncthreads();
+                const u32 t0 = top[0];
+                const u32 m1 = dme_wave_max_u32(key == t0 ? 0u : key);
+                if (lane == 0 && m1) atomicMax(&top[1], m1);
+                if (tid < CB) h[tid] = 0;
+                __syncthreads();
+                const u32 t1 = top[1];
+                if ((t0 >> COLBITS) >= (u32)HOT_MIN) hot0 = t0 & cmask;
+                if ((t1 >> COLBITS) >= (u32)HOT_MIN) hot1 = t1 & cmask;
+            }
+            double a0 = 0.0, a1 = 0.0;  // this thread's share of the frequent columns' mean accumulators
             // Counts beyond the bins and row totals beyond the weight table: one record at a time,
             // only in waves that hold such a record (head-of-vocabulary columns, very long rows).
             auto rare_one = [&](u32 rec) {
@@ -1163,20 +1219,8 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                 if (v == 0) return;
                 const u32 cl = rec & cmask;
                 const u32 tot = rec >> (COLBITS + VBITS);
-                if (v > (u32)a.BL) {
-                    const u32 key = ((cl << VBITS) | v) + 1u;
-                    u32 slot = (key * 2654435761u) >> (32 - 11);  // OVF = 2^11
-                    bool placed = false;
-                    for (int probe = 0; probe < 16 && !placed; ++probe) {
-                        const u32 old = atomicCAS(&okey[slot], 0u, key);
-                        if (old == 0u || old == key) {
-                            atomicAdd(&ocnt[slot], 1u);
-                            placed = true;
-                        }
-                        slot = (slot + 1) & (OVF - 1);
-                    }
-                    if (!placed) atomicAdd(&a.hist[(kbase + cl) * a.nbins + v], 1ULL);  // table crowded
-                }
+                const bool hot = cl == hot0 || cl == hot1;
+                if (v > (u32)a.BL && !hot) add_cell(cl, v, 1u, kbase);
                 if (tot >= (u32)WTAB) {
                     const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)tot));
                     __hip_atomic_fetch_add(&acc[((u32)tid & acmask) * CB + cl], __dmul_rn((double)v, w),
@@ -1187,8 +1231,7 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
             // the loads of the next eight are in flight while the current eight are counted.  The eight
             // records of a buffer go through the LDS pipe side by side (eight weight reads, one wait,
             // eight counter adds, eight accumulator adds): taken one record at a time, every record paid
-            // the latency of its own weight read (2.18 ms for the 12.5 M-row shard; the LDS operations
-            // themselves need 0.6 ms, benchmarks/micro/lds_atomics.hip).
+            // the latency of its own weight read.
             constexpr int D = 8;
             u32 vzero;  // a zero the compiler cannot see: keeps the chunk list's loads vector loads
             asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
@@ -1203,6 +1246,7 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                                  : 0u;
             };
             double* const acc_mine = acc + ((u32)tid & acmask) * CB;
+            u32* const hh_mine = hh + (lane & (HC - 1));
             auto count = [&](const u32 (&rec)[D]) {
                 u32 v[D], cl[D];
                 double w[D];
@@ -1212,17 +1256,25 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                     v[q] = (rec[q] >> COLBITS) & (VLIM - 1);
                     cl[q] = rec[q] & cmask;
                     const u32 tot = rec[q] >> (COLBITS + VBITS);
-                    rare |= v[q] > (u32)a.BL || tot >= (u32)WTAB;
                     w[q] = wtab[tot < (u32)WTAB ? tot : 0u];
                 }
 #pragma unroll
-                for (int q = 0; q < D; ++q)
-                    if (v[q] - 1u < (u32)a.BL) atomicAdd(&h[(v[q] - 1) * CB + cl[q]], 1u);  // bin-major: bank = column
-#pragma unroll
-                for (int q = 0; q < D; ++q)
-                    if (v[q] != 0 && (rec[q] >> (COLBITS + VBITS)) < (u32)WTAB)
-                        __hip_atomic_fetch_add(&acc_mine[cl[q]], __dmul_rn((double)v[q], w[q]), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int q = 0; q < D; ++q) {
+                    const bool is0 = cl[q] == hot0, is1 = cl[q] == hot1;
+                    const bool hot = is0 || is1;
+                    const bool intab = (rec[q] >> (COLBITS + VBITS)) < (u32)WTAB;
+                    rare |= (v[q] > (u32)a.BL && !hot) || !intab;
+                    const double x = intab ? __dmul_rn((double)v[q], w[q]) : 0.0;
+                    if (hot) {  // count 0 (a slot beyond the chunk's fill) lands in bin 0 of the table, which nobody reads
+                        atomicAdd(&hh_mine[((is1 ? VLIM : 0u) + v[q]) * HC], 1u);
+                    } else {
+                        if (v[q] - 1u < (u32)a.BL) atomicAdd(&h[(v[q] - 1) * CB + cl[q]], 1u);  // bin-major: bank = column
+                        if (v[q] != 0 && intab)
+                            __hip_atomic_fetch_add(&acc_mine[cl[q]], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    a0 = __dadd_rn(a0, is0 ? x : 0.0);
+                    a1 = __dadd_rn(a1, is1 ? x : 0.0);
+                }
                 if (__any(rare)) {
 #pragma unroll
                     for (int q = 0; q < D; ++q) rare_one(rec[q]);
@@ -1240,6 +1292,24 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                 count(rb);
                 ci += D;
                 if (ci >= seg_end) break;
+            }
+            // ---- the frequent columns join the image ------------------------------------------------------------
+            a0 = dme_wave_sum_f64(a0);
+            a1 = dme_wave_sum_f64(a1);
+            __syncthreads();
+            if (lane == 0) {
+                if (hot0 != 0xFFFFFFFFu && a0 != 0.0)
+                    __hip_atomic_fetch_add(&acc[hot0], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hot1 != 0xFFFFFFFFu && a1 != 0.0)
+                    __hip_atomic_fetch_add(&acc[hot1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (tid < HOT * (int)VLIM) {
+                const u32 v = (u32)tid & (VLIM - 1);
+                const u32 col = tid < (int)VLIM ? hot0 : hot1;
+                u32 n = 0;
+#pragma unroll
+                for (int q = 0; q < HC; ++q) n += hh[tid * HC + q];
+                if (n && v && col != 0xFFFFFFFFu) add_cell(col, v, n, kbase);
             }
             __syncthreads();
             // The run (b, piece) is the (b + piece)-th of the list: runs are ordered and each one
@@ -1364,7 +1434,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
                                           (int)(sizeof(WaveStage) * PWAVES + 4 * TBL)));
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr2_bucket_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          IMAGE_LDS_BYTES + 8 * WTAB));
+                                          IMAGE_LDS_BYTES + 8 * WTAB + HOT_LDS_BYTES));
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr3_part_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(TileLds) + 4 * TBL)));
@@ -1393,7 +1463,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     bk.hist = hist; bk.init_acc = init_acc; bk.status = status;
     bk.images = ws + p.off_images;
     bk.image_bytes = p.image_bytes;
-    hipLaunchKernelGGL(csr2_bucket_kernel, dim3(p.W), dim3(BBLOCK), (size_t)p.image_bytes + 8 * WTAB, s, bk);
+    hipLaunchKernelGGL(csr2_bucket_kernel, dim3(p.W), dim3(BBLOCK), (size_t)p.image_bytes + 8 * WTAB + HOT_LDS_BYTES, s, bk);
     hipLaunchKernelGGL(csr2_reduce_kernel, dim3(p.NB, (p.CB * p.BL + BBLOCK - 1) / BBLOCK),
                        dim3(BBLOCK), 0, s, bk);
     DME_HIP_CHECK(hipGetLastError());

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--solve", action="store_true")
     ap.add_argument("--no-shuffle", action="store_true")
+    ap.add_argument("--zipf-s", type=float, default=1.07,
+                    help="exponent of the word weights (1.07 = BASELINE configs[3]; 0 = no frequent words: an experiment)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--dense-message", action="store_true",
                     help="all-reduce K x nbins words instead of the occupied bins of every column")
@@ -129,7 +131,7 @@ def main():
             dist.init_process_group(args.backend)
 
     t0 = time.time()
-    rowptr, colidx, vals = generate(args.rows, args.k, seed=20260004 + rank,
+    rowptr, colidx, vals = generate(args.rows, args.k, seed=20260004 + rank, s=args.zipf_s,
                                     shuffle_columns=not args.no_shuffle)
     torch.cuda.synchronize()
     t_gen = time.time() - t0

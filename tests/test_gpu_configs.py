@@ -159,17 +159,19 @@ def test_config4_csr_shard_scale_properties():
     lens = rowptr[1:] - rowptr[:-1]
     w = 1.0 / (1.0 + totals.to(torch.float64))
     # (blocks of 2^18 rows summed on their own, then the blocks pairwise: a single running fp64 sum of
-    # 1e7 terms would itself be off by more than the bar)
+    # 1e7 terms would itself be off by more than the bar; 64 accumulators per column, chosen by the
+    # entry's position: fp64 atomics of a whole block on one frequent word's cell take minutes)
     parts = []
-    row_step = 1 << 18
+    row_step, R = 1 << 18, 64
     for r0 in range(0, N, row_step):
         r1 = min(N, r0 + row_step)
         e0, e1 = int(rowptr[r0]), int(rowptr[r1])
         we = torch.repeat_interleave(w[r0:r1], lens[r0:r1], output_size=e1 - e0)
-        part = torch.zeros(K, dtype=torch.float64, device="cuda")
-        part.index_add_(0, colidx[e0:e1].to(torch.int64), we * vals[e0:e1].to(torch.float64))
-        parts.append(part)
-        del we
+        part = torch.zeros(K * R, dtype=torch.float64, device="cuda")
+        idx = colidx[e0:e1].to(torch.int64) * R + (torch.arange(e1 - e0, device="cuda") % R)
+        part.index_add_(0, idx, we * vals[e0:e1].to(torch.float64))
+        parts.append(part.view(K, R).sum(dim=1))
+        del we, idx, part
     acc = torch.stack(parts).sum(dim=0)
     del parts
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), acc.cpu().numpy(), rtol=1e-11, atol=0)
