@@ -52,9 +52,18 @@ constexpr int OVF = 2048;              // slots of an image's overflow table (co
 #define DME_CSR2_PIECES_PER_CU 4
 #endif
 
-#ifndef DME_CSR3_WGS_PER_CU
-#define DME_CSR3_WGS_PER_CU 2
+// the tile partition kernel (csr3_part_kernel below)
+#ifndef DME_CSR3_T3
+#define DME_CSR3_T3 512
 #endif
+#ifndef DME_CSR3_WGS_PER_CU
+#define DME_CSR3_WGS_PER_CU (1024 / DME_CSR3_T3)
+#endif
+constexpr int T3 = DME_CSR3_T3;       // threads of a tile workgroup (at most 512)
+constexpr int T3W = T3 / 64;
+constexpr int EPT = 8;                // entries per thread
+constexpr int TILE = T3 * EPT;        // entries per tile
+constexpr int RW = T3;                // rows of a tile's window (one per thread)
 
 struct Plan {
     int sh, CB, NB, BL, AC, G, W;
@@ -97,7 +106,7 @@ inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan*
     p->max_chunks = (nnz + CHUNK - 1) / CHUNK + G * ((long long)PWAVES * p->NB + 2) + 64;
     // the tile kernel: G3 workgroups with ceil(nnz / G3) entries each at most; every bucket's stream may
     // leave one chunk partly filled
-    long long G3 = (nnz + 4LL * 4096 - 1) / (4LL * 4096);
+    long long G3 = (nnz + 4LL * TILE - 1) / (4LL * TILE);
     if (G3 > (long long)cus * DME_CSR3_WGS_PER_CU) G3 = (long long)cus * DME_CSR3_WGS_PER_CU;
     if (G3 < 1) G3 = 1;
     p->G3 = (int)G3;
@@ -116,7 +125,7 @@ inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan*
     p->off_bcount = o;   o = align256(o + 4 * MAXB);
     p->off_bpos = o;     o = align256(o + 4 * MAXB);
     p->off_images = o;   o = align256(o + (long long)(p->NB + p->W) * p->image_bytes);
-    p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL + (long long)p->G3 * 4096 * 4LL);  // + the tile kernel's dump areas
+    p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL + (long long)p->G3 * TILE * 4LL);  // + the tile kernel's dump areas
     p->bytes = o;
     return true;
 }
@@ -501,11 +510,6 @@ __global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
 #define TS_FLUSH(p)
 #endif
 
-constexpr int T3 = 512;               // threads of a tile workgroup
-constexpr int T3W = T3 / 64;
-constexpr int EPT = 8;                // entries per thread
-constexpr int TILE = T3 * EPT;        // entries per tile
-constexpr int RW = T3;                // rows of a tile's window (one per thread)
 constexpr u32 HUGE_V = 1u << 19;      // counts from here on: row totals are added up in 64 bits, row by row
 
 struct TileArgs {
@@ -567,12 +571,12 @@ struct TileLds {
     // per bucket {first staged position of its run, records that still fit the stream's open chunk,
     // destination of the run's record 0 in that chunk, destination of record 0 in the chunks taken for
     // this tile (their ids are consecutive)}: destination of record i = i < .y ? .z + i : .w + i
-    u32x4v prm[MAXB];
+    u32x4v prm[MAXB + 1];
+    unsigned char SB[TILE];  // bucket of every staged record (8-byte aligned: reset eight slots at a time)
     u32 staged;           // records of the tile in the staging area
-    unsigned char SB[TILE];  // bucket of every staged record
     u32 len[MAXB];        // records written to the bucket's stream so far
     u32 cur[MAXB];        // id of the stream's last chunk
-    u32 wsum[T3W], wrows[T3W];
+    u32 wsum[8], wrows[8];   // per wave (T3W <= 8; the rest stays 0)
     u32 WR[T3W];          // window index + 1 of the row that holds the entry in front of wave w's first
     u32 straddle;         // window index + 1 of the row that runs over the tile's end
     u32 wg_next;          // chunk ids taken from the workgroup's range
@@ -631,6 +635,10 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     }
     if (tid < 8) L.stat[tid] = 0;
     if (tid < T3W) L.WR[tid] = 0;
+    if (tid < 8) {
+        L.wsum[tid] = 0;
+        L.wrows[tid] = 0;
+    }
     if (tid == 0) {
         L.straddle = 0;
         L.cut = 0xFFFFFFFFu;
@@ -698,6 +706,9 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         return dme_wave_sum_u64(s);
     };
 
+    // staging slots nobody filled are stored too (always eight stores per thread: the wait for the next
+    // tile's loads, issued before them, can then count them out): to this workgroup's dump area behind the pool
+    const u32 dump = (u32)(a.max_chunks << 10) + (u32)g * TILE;
     u32 nq0, nq1, nqrw;
     u32 nc[EPT], nv[EPT];
     load_window(jb, nq0, nq1, nqrw);
@@ -738,20 +749,20 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         const bool owned = vrow && tid >= jrel && !cut_here && (exhausted || s0 < n0 || (last && apos + (u32)n0 >= E1));
 
         // ---- P1 ------------------------------------------------------------------------------------------
+        // (entries behind the tile's end are summed too: the sums behind it are not read; a count of 2^19 or
+        // more anywhere sends the tile's row totals down the 64-bit path, so the 32-bit sums may then wrap)
         u32 vp[EPT];
-        u32 tsum = 0;
-        bool hg = false;
+        u32 tsum = 0, orv = 0;
         const int k0 = tid * EPT;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-            const bool in = k0 + i < n0;  // beyond a cut the sums are not read
             const int x = (int)v[i];
-            u32 pv = in && x > 0 ? (u32)x : 0u;
-            hg |= pv >= HUGE_V;
-            if (pv > HUGE_V) pv = HUGE_V;
+            const u32 pv = x > 0 ? (u32)x : 0u;
+            orv |= pv;
             vp[i] = tsum;  // exclusive inside the thread
             tsum += pv;
         }
+        const bool hg = orv >= HUGE_V;
         const u32 incl = dme_wave_incl_scan_u32(tsum);
         if (lane == 63) L.wsum[wave] = incl;
         {
@@ -807,22 +818,28 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
             // entries start out in this row
             for (int w = s_rel < 0 ? 1 : (s_rel >> 9) + 1; w < T3W && (w << 9) <= t_rel; ++w) L.WR[w] = (u32)tid + 1;
         }
-        u32 okm = 0;  // bit i: entry i goes to the staging area
+        u32 okm = 0;  // bit i: entry i goes to the staging area; bit 31: an entry that does not (and is not a zero)
         {
             // eight returning adds side by side, one wait (entries that are not staged add to a sink word:
             // a branch around each add made every one of them wait for its own result)
             u32 rk[EPT];
+            u32 nonok = 0;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
-                const bool in = k0 + i < n_ent;
-                const bool ok = in && v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
+                v[i] = k0 + i < n_ent ? v[i] : 0u;  // entries behind the tile's end: zeros from here on
+                const bool ok = v[i] - 1u < vmax - 1u && c[i] < (u32)a.K;  // count in 1 .. vmax - 1, column in range
                 okm |= ok ? 1u << i : 0u;
+                const u32 vm = ok ? v[i] : 0u;
+                maxv = vm > maxv ? vm : maxv;
+                nonok |= v[i] ^ vm;  // != 0: a count that is there and is not staged
                 rk[i] = atomicAdd(&L.cnt[ok ? c[i] >> a.sh : (u32)MAXB], 1u);
             }
+            okm |= nonok ? 0x80000000u : 0u;
             // its number in its bucket's run rides above the count (< 256) from here on
 #pragma unroll
             for (int i = 0; i < EPT; ++i) v[i] |= (okm >> i) & 1u ? rk[i] << VBITS : 0u;
         }
+        *(u64*)&L.SB[k0] = 0x4040404040404040ull;  // every staging slot: the sink bucket, until P4 fills it
         if (wave == 0 && jrel == 1) {  // window row 0 began before the tile: its entries in front of it
             const u64 x = wave_row_part(rp[2 * jb], apos);
             if (lane == 0) L.head_extra = x;
@@ -844,8 +861,9 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
             const u32 lo = L.len[lane];
             const u32 curold = L.cur[lane];
             const u32 firstnew = (lo + CHUNK - 1) >> 10;            // chunks the stream has opened so far
-            u32 d0 = curold == 0xFFFFFFFFu ? 0xFFFFFC00u : (curold << 10) + (lo & (CHUNK - 1));
-            u32 d1 = 0xF0000000u;                                   // no chunk: beyond every pool, not stored
+            // (a stream without a chunk, which only a pool that ran out can cause, is sent to the dump area)
+            u32 d0 = curold == 0xFFFFFFFFu ? dump + (inc - m) : (curold << 10) + (lo & (CHUNK - 1));
+            u32 d1 = dump + (inc - m);
             const u32 split = (firstnew << 10) - lo;                // 0 when the open chunk is full (or none is open)
             if (m > 0) {
                 const u32 lastcn = (lo + m - 1) >> 10;              // chunk number of the run's last record
@@ -868,6 +886,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                 L.len[lane] = lo + m;
             }
             L.prm[lane] = u32x4v{inc - m, split, d0, d1};
+            if (lane == 0) L.prm[MAXB] = u32x4v{0u, 0u, dump, dump};  // the sink bucket: slot i goes to dump + i
         }
         if (vrow && (owned || (tid == 0 && jrel == 1))) {  // row totals (DE/dme.py:121 sum(row))
             u64 total;
@@ -939,10 +958,9 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                 tot[i] = L.RT32[ri];
                 ofs[i] = L.prm[(c[i] >> a.sh) & (MAXB - 1)].x;
             }
-            bool rare = false;
+            u32 tmx = 0;
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
-                const bool in = k0 + i < n_ent;
                 const bool ok = (okm >> i) & 1u;
                 const bool fits = tot[i] < TLIM;
                 const u32 cnt8 = v[i] & (VLIM - 1), rank = v[i] >> VBITS;  // of an entry with `ok`
@@ -950,16 +968,16 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                 if (ok) {
                     L.PX[ofs[i] + rank] = rec;  // a record with count 0 is skipped by the bucket pass
                     L.SB[ofs[i] + rank] = (unsigned char)(c[i] >> a.sh);
-                    maxv = cnt8 > maxv ? cnt8 : maxv;
                 }
-                rare |= in && v[i] != 0 && !(ok && fits);
+                tmx = tot[i] > tmx ? tot[i] : tmx;
             }
+            // an entry that is not staged, or a row total a record cannot hold (of any of the eight rows)
+            const bool rare = (okm >> 31) != 0 || tmx >= TLIM;
             if (__any(rare)) {
 #pragma unroll 1
                 for (int i = 0; i < EPT; ++i) {
-                    const bool in = k0 + i < n_ent;
                     const bool ok = (okm >> i) & 1u;
-                    if (!in || v[i] == 0 || (ok && tot[i] < TLIM)) continue;
+                    if (v[i] == 0 || (ok && tot[i] < TLIM)) continue;
                     const u32 cnt = ok ? v[i] & (VLIM - 1) : v[i];
                     if ((int)cnt > 0 && c[i] < (u32)a.K) maxv = cnt > maxv ? cnt : maxv;
                     const int r = csr3_rare_entry(a.hist, a.init_acc, a.nbins, a.K, c[i], cnt, L.RT[f[i]]);
@@ -976,11 +994,8 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         {
             // thread t takes the staged records t, t + 512, ...: neighbours in a run are neighbours in the
             // bucket's stream, so a wave's store covers a few contiguous pieces
-            const u32 staged = uni(L.staged);
-            const u32 dlimit = (u32)(a.max_chunks << 10);
-            const u32 dump = dlimit + (u32)g * TILE;
             if (tid < T3W) L.WR[tid] = 0;  // read in P4, written again in the next tile's P2
-            u32 t2 = (u32)tid;  // opaque: keeps the eight positions and dump slots from being held (and spilled) across the loop
+            u32 t2 = (u32)tid;  // opaque: keeps the eight positions from being held (and spilled) across the loop
             asm volatile("" : "+v"(t2));
             u32 rec[EPT], bk[EPT];
 #pragma unroll
@@ -992,14 +1007,9 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
                 const u32 pos = (u32)(k * T3) + t2;
-                const u32x4v pr = L.prm[bk[k] & (MAXB - 1)];
+                const u32x4v pr = L.prm[bk[k]];
                 const u32 i = pos - pr.x;
-                u32 dst = i < pr.y ? pr.z + i : pr.w + i;
-                // always eight stores (slots nobody staged go to the workgroup's dump area behind the pool):
-                // the wait for the next tile's loads, issued before them, can then count them out
-                // instead of waiting for their acknowledgements too
-                if (!(pos < staged && dst < dlimit)) dst = dump + pos;
-                a.chunks[dst] = rec[k];
+                a.chunks[i < pr.y ? pr.z + i : pr.w + i] = rec[k];
             }
         }
         TS_MARK(4)
@@ -1129,7 +1139,10 @@ __device__ __forceinline__ u32 piece_chunks(u32 total, int W) { return (total + 
 // out of the shared cells: their mean accumulators are registers of every thread (summed over the
 // workgroup at the end of the run), their counts go to a table of their own with HC copies of every bin,
 // the lane's copy chosen by its number.  Which columns are picked changes the speed only.
-constexpr int HOT = 2;   // frequent columns per run
+#ifndef DME_CSR2_HOT
+#define DME_CSR2_HOT 2
+#endif
+constexpr int HOT = DME_CSR2_HOT;   // frequent columns per run
 constexpr int HC = 8;    // copies of a frequent column's bins
 constexpr int HOT_MIN = 16;  // occurrences in the first chunk that make a column frequent
 constexpr int HOT_LDS_BYTES = HOT * (int)VLIM * HC * 4 + 64;
@@ -1192,26 +1205,34 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
             __syncthreads();
             const long long kbase = (long long)b << a.sh;
             // ---- the run's frequent columns: the first chunk counted by column in the first bin row ----------
-            u32 hot0 = 0xFFFFFFFFu, hot1 = 0xFFFFFFFFu;
+            u32 hotc[HOT];
             {
                 const u32 se = a.sorted[pos];
                 const u32 rec = (u32)tid <= (se >> IDBITS) ? a.chunks[(long long)(se & ((1u << IDBITS) - 1)) * CHUNK + tid] : 0u;
                 if ((rec >> COLBITS) & (VLIM - 1)) atomicAdd(&h[rec & cmask], 1u);
                 __syncthreads();
-                const u32 key = tid < CB ? (h[tid] << COLBITS) | (u32)tid : 0u;
-                const u32 m0 = dme_wave_max_u32(key);
-                if (lane == 0 && m0) atomicMax(&top[0], m0);
+                u32 key = tid < CB ? (h[tid] << COLBITS) | (u32)tid : 0u;
                 __syncthreads();
-                const u32 t0 = top[0];
-                const u32 m1 = dme_wave_max_u32(key == t0 ? 0u : key);
-                if (lane == 0 && m1) atomicMax(&top[1], m1);
                 if (tid < CB) h[tid] = 0;
-                __syncthreads();
-                const u32 t1 = top[1];
-                if ((t0 >> COLBITS) >= (u32)HOT_MIN) hot0 = t0 & cmask;
-                if ((t1 >> COLBITS) >= (u32)HOT_MIN) hot1 = t1 & cmask;
+#pragma unroll
+                for (int k = 0; k < HOT; ++k) {  // the largest key, then the largest of the rest, ...
+                    const u32 m = dme_wave_max_u32(key);
+                    if (lane == 0 && m) atomicMax(&top[k], m);
+                    __syncthreads();
+                    const u32 t = top[k];
+                    hotc[k] = (t >> COLBITS) >= (u32)HOT_MIN ? t & cmask : 0xFFFFFFFFu;
+                    if (key == t) key = 0;
+                }
             }
-            double a0 = 0.0, a1 = 0.0;  // this thread's share of the frequent columns' mean accumulators
+            double ah[HOT];  // this thread's share of the frequent columns' mean accumulators
+#pragma unroll
+            for (int k = 0; k < HOT; ++k) ah[k] = 0.0;
+            auto hot_index = [&](u32 cl) -> int {
+                int r = -1;
+#pragma unroll
+                for (int k = 0; k < HOT; ++k) r = cl == hotc[k] ? k : r;
+                return r;
+            };
             // Counts beyond the bins and row totals beyond the weight table: one record at a time,
             // only in waves that hold such a record (head-of-vocabulary columns, very long rows).
             auto rare_one = [&](u32 rec) {
@@ -1219,7 +1240,7 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                 if (v == 0) return;
                 const u32 cl = rec & cmask;
                 const u32 tot = rec >> (COLBITS + VBITS);
-                const bool hot = cl == hot0 || cl == hot1;
+                const bool hot = hot_index(cl) >= 0;
                 if (v > (u32)a.BL && !hot) add_cell(cl, v, 1u, kbase);
                 if (tot >= (u32)WTAB) {
                     const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)tot));
@@ -1260,20 +1281,20 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                 }
 #pragma unroll
                 for (int q = 0; q < D; ++q) {
-                    const bool is0 = cl[q] == hot0, is1 = cl[q] == hot1;
-                    const bool hot = is0 || is1;
+                    const int hi = hot_index(cl[q]);
+                    const bool hot = hi >= 0;
                     const bool intab = (rec[q] >> (COLBITS + VBITS)) < (u32)WTAB;
                     rare |= (v[q] > (u32)a.BL && !hot) || !intab;
                     const double x = intab ? __dmul_rn((double)v[q], w[q]) : 0.0;
                     if (hot) {  // count 0 (a slot beyond the chunk's fill) lands in bin 0 of the table, which nobody reads
-                        atomicAdd(&hh_mine[((is1 ? VLIM : 0u) + v[q]) * HC], 1u);
+                        atomicAdd(&hh_mine[((u32)hi * VLIM + v[q]) * HC], 1u);
                     } else {
                         if (v[q] - 1u < (u32)a.BL) atomicAdd(&h[(v[q] - 1) * CB + cl[q]], 1u);  // bin-major: bank = column
                         if (v[q] != 0 && intab)
                             __hip_atomic_fetch_add(&acc_mine[cl[q]], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    a0 = __dadd_rn(a0, is0 ? x : 0.0);
-                    a1 = __dadd_rn(a1, is1 ? x : 0.0);
+#pragma unroll
+                    for (int k = 0; k < HOT; ++k) ah[k] = __dadd_rn(ah[k], hi == k ? x : 0.0);
                 }
                 if (__any(rare)) {
 #pragma unroll
@@ -1294,21 +1315,23 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
                 if (ci >= seg_end) break;
             }
             // ---- the frequent columns join the image ------------------------------------------------------------
-            a0 = dme_wave_sum_f64(a0);
-            a1 = dme_wave_sum_f64(a1);
+#pragma unroll
+            for (int k = 0; k < HOT; ++k) ah[k] = dme_wave_sum_f64(ah[k]);
             __syncthreads();
             if (lane == 0) {
-                if (hot0 != 0xFFFFFFFFu && a0 != 0.0)
-                    __hip_atomic_fetch_add(&acc[hot0], a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hot1 != 0xFFFFFFFFu && a1 != 0.0)
-                    __hip_atomic_fetch_add(&acc[hot1], a1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int k = 0; k < HOT; ++k)
+                    if (hotc[k] != 0xFFFFFFFFu && ah[k] != 0.0)
+                        __hip_atomic_fetch_add(&acc[hotc[k]], ah[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (tid < HOT * (int)VLIM) {
-                const u32 v = (u32)tid & (VLIM - 1);
-                const u32 col = tid < (int)VLIM ? hot0 : hot1;
+            for (int t = tid; t < HOT * (int)VLIM; t += BBLOCK) {
+                const u32 v = (u32)t & (VLIM - 1);
+                u32 col = 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < HOT; ++k) col = (t >> VBITS) == k ? hotc[k] : col;
                 u32 n = 0;
 #pragma unroll
-                for (int q = 0; q < HC; ++q) n += hh[tid * HC + q];
+                for (int q = 0; q < HC; ++q) n += hh[t * HC + q];
                 if (n && v && col != 0xFFFFFFFFu) add_cell(col, v, n, kbase);
             }
             __syncthreads();
