@@ -1520,13 +1520,21 @@ int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first,
 // still runs, so its launches cost the host nothing, but a launch that finds the solve finished still
 // costs ~5 us of device time and a batch that falls short a host round trip (~25 us): the first batch
 // covers what this thread's previous solve of the same shape needed plus one spare, 16 evaluations
-// otherwise.
-thread_local long long hint_K = -1, hint_ldU = -1, hint_launches = 0;
+// otherwise; the spare is dropped once two solves in a row of that shape needed the same number (a
+// series that has settled, such as re-estimation of the same statistics).
+thread_local long long hint_K = -1, hint_ldU = -1, hint_launches = 0, hint_repeats = 0;
+
+void remember_solve(long long K, long long ldU, long long launches) {
+    hint_repeats = (hint_K == K && hint_ldU == ldU && hint_launches == launches) ? hint_repeats + 1 : 0;
+    hint_K = K;
+    hint_ldU = ldU;
+    hint_launches = launches;
+}
 
 long long first_batch(long long K, long long ldU, int path) {
     long long evals = 16;
     if (hint_K == K && hint_ldU == ldU && hint_launches > 0) {
-        evals = hint_launches + 1;
+        evals = hint_launches + (hint_repeats >= 1 ? 0 : 1);
         if (evals < 4) evals = 4;
         if (evals > 32) evals = 32;
     }
@@ -1571,9 +1579,7 @@ int solve_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_
             return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", launched);
         batch = launched < 64 ? 8 : 32;
     }
-    hint_K = c.K;
-    hint_ldU = c.ldU;
-    hint_launches = pinned[4];  // evaluations' worth of launches that did work
+    remember_solve(c.K, c.ldU, pinned[4]);  // evaluations' worth of launches that did work
     if (result_host)
         for (int i = 0; i < 8; ++i) result_host[i] = pinned[i];
     return result_error(pinned);
@@ -1635,8 +1641,6 @@ extern "C" int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* l
 extern "C" int dme_solve_finish(const int64_t* result_host, int64_t K, int64_t ldU) {
     DME_REQUIRE(result_host != nullptr, "null pointer");
     if (!result_host[6]) return DME_OK;  // not done: the caller enqueues more launches
-    hint_K = K;
-    hint_ldU = ldU;
-    hint_launches = result_host[4];
+    remember_solve(K, ldU, result_host[4]);
     return result_error((const long long*)result_host);
 }
