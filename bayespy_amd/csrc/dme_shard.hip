@@ -64,19 +64,18 @@ __global__ __launch_bounds__(SHARD_BLOCK) void shard_unpack_kernel(u64* msg, lon
 }
 
 // The same message in 32-bit words, for jobs of fewer than 2^32 rows (no bin can hold more than the
-// job's rows): hist and histV take one word per bin, every other 64-bit word travels as (lo, hi).
-// Half the bytes of the 64-bit message on the wire.  The additive status words are saturated at
-// (2^32 - 1) / world per rank so that their low words cannot wrap in the sum (the row count is below
-// 2^32 by the caller's promise; the others are error counters, where any non-zero value is the news).
-__device__ __forceinline__ u64 shard_sat(u64 x, u64 cap) { return x > cap ? cap : x; }
-
+// job's rows): hist and histV take one word per bin.  Everything else is 64-bit and travels as (lo, hi)
+// word pairs, which a 32-bit SUM can only transport, not add (a carry out of the low word is lost): so a
+// rank's eight status words ride in its OWN slot row, in front of its mean accumulators,
+//     msg32 = hist[nh] | histV[nv] | slots[world][8 + K] as (lo, hi)
+// every other rank's row is 0, and the sum hands every rank all rows unchanged.  unpack32 adds the
+// additive status words in 64 bits (exact whatever the shards' sizes) and takes the maxima.
 __global__ __launch_bounds__(SHARD_BLOCK) void shard_pack32_kernel(
     const u64* hist, long long nh, const u64* histV, long long nv, const u64* status,
     const double* init_acc, long long K, long long rank, long long world, u32* msg) {
     const long long nb = nh + nv;
-    const long long total = nb + 2 * (8 + world * (2 + K));
+    const long long total = nb + 2 * world * (8 + K);
     const long long stride = (long long)gridDim.x * SHARD_BLOCK;
-    const u64 cap = 0xFFFFFFFFULL / (u64)world;
     for (long long i = (long long)blockIdx.x * SHARD_BLOCK + threadIdx.x; i < total; i += stride) {
         u32 x;
         if (i < nh) {
@@ -84,18 +83,13 @@ __global__ __launch_bounds__(SHARD_BLOCK) void shard_pack32_kernel(
         } else if (i < nb) {
             x = (u32)histV[i - nh];
         } else {
-            const long long w = (i - nb) >> 1;  // 64-bit word index behind the bins
+            const long long q = (i - nb) >> 1;  // 64-bit word index behind the bins
             const int half = (int)((i - nb) & 1);
+            const long long r = q / (8 + K), j = q - r * (8 + K);
             u64 v;
-            if (w < 8) {
-                v = (w == 4 || w == 5) ? 0ULL : shard_sat(status[w], cap);
-            } else {
-                const long long q = w - 8;
-                const long long r = q / (2 + K), j = q - r * (2 + K);
-                if (r != rank) v = 0ULL;
-                else if (j < 2) v = status[4 + j];
-                else v = (u64)__double_as_longlong(init_acc[j - 2]);
-            }
+            if (r != rank) v = 0ULL;
+            else if (j < 8) v = status[j];
+            else v = (u64)__double_as_longlong(init_acc[j - 8]);
             x = half ? (u32)(v >> 32) : (u32)v;
         }
         msg[i] = x;
@@ -103,7 +97,7 @@ __global__ __launch_bounds__(SHARD_BLOCK) void shard_pack32_kernel(
 }
 
 // After the all-reduce: widens the bins into hist64 / histV64 (what dme_suffix_scan reads), rebuilds
-// status[8] (maxima over the ranks' slots) and adds the mean accumulators in rank order.
+// status[8] (sums and maxima over the ranks' slot rows) and adds the mean accumulators in rank order.
 __global__ __launch_bounds__(SHARD_BLOCK) void shard_unpack32_kernel(
     const u32* msg, long long nh, long long nv, long long K, long long world, u64* hist64,
     u64* histV64, u64* status, double* init_acc) {
@@ -118,22 +112,18 @@ __global__ __launch_bounds__(SHARD_BLOCK) void shard_unpack32_kernel(
     const u32* tail = msg + nb;
     auto word = [&](long long w) { return (u64)tail[2 * w] | ((u64)tail[2 * w + 1] << 32); };
     if (t0 < 8) {
-        u64 v;
-        if (t0 == 4 || t0 == 5) {
-            v = 0;
-            for (long long r = 0; r < world; ++r) {
-                const u64 x = word(8 + r * (2 + K) + (t0 - 4));
-                v = x > v ? x : v;
-            }
-        } else {
-            v = word(t0);
+        u64 v = 0;
+        for (long long r = 0; r < world; ++r) {
+            const u64 x = word(r * (8 + K) + t0);
+            if (t0 == 4 || t0 == 5) v = x > v ? x : v;  // the observed maxima
+            else v += x;
         }
         status[t0] = v;
     }
     for (long long k = t0; k < K; k += stride) {
-        double s = __longlong_as_double((long long)word(8 + 2 + k));
+        double s = __longlong_as_double((long long)word(8 + k));
         for (long long r = 1; r < world; ++r)  // rank order: the same bits on every rank
-            s = __dadd_rn(s, __longlong_as_double((long long)word(8 + r * (2 + K) + 2 + k)));
+            s = __dadd_rn(s, __longlong_as_double((long long)word(r * (8 + K) + 8 + k)));
         init_acc[k] = s;
     }
 }
@@ -255,7 +245,7 @@ extern "C" int dme_shard_expand(const uint64_t* compact, int64_t K, int64_t nbin
 
 extern "C" int64_t dme_shard_message_words32(int64_t nh, int64_t nv, int64_t K, int64_t world) {
     if (nh < 0 || nv < 0 || K < 1 || world < 1) return -1;
-    return nh + nv + 2 * (8 + world * (2 + K));
+    return nh + nv + 2 * world * (8 + K);
 }
 
 extern "C" int dme_shard_pack32(const uint64_t* hist, int64_t nh, const uint64_t* histV, int64_t nv,
@@ -266,7 +256,7 @@ extern "C" int dme_shard_pack32(const uint64_t* hist, int64_t nh, const uint64_t
     DME_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bad rank %lld of %lld", (long long)rank,
                 (long long)world);
     DME_REQUIRE((nh == 0 || hist) && (nv == 0 || histV) && status && init_acc && msg, "null pointer");
-    const long long total = nh + nv + 2 * (8 + world * (2 + K));
+    const long long total = nh + nv + 2 * world * (8 + K);
     long long grid = (total + SHARD_BLOCK * 4 - 1) / (SHARD_BLOCK * 4);
     if (grid > 2048) grid = 2048;
     if (grid < 1) grid = 1;

@@ -450,6 +450,11 @@ class DeviceStats:
                 f"statistics incomplete: {int(st[1])} cells >= {self.nbins} and {int(st[2])} row "
                 f"totals >= {self.tbins} (largest seen: count {int(st[4])}, total {int(st[5])}); "
                 "max_count / max_total passed to add_* were too small")
+        bound = getattr(self, "_rows_bound", None)
+        if bound is not None and int(st[0]) > bound:
+            raise ValueError(
+                f"the ranks counted {int(st[0])} rows, more than the rows_bound={bound} promised to "
+                "allreduce(): the histograms travelled in 32-bit words and a bin may have wrapped")
         return {"rows": int(st[0]), "max_count": int(st[4]), "max_total": int(st[5])}
 
     @property
@@ -468,6 +473,8 @@ class DeviceStats:
         the message size.  After it every rank holds the global statistics and solves redundantly;
         there is no per-iteration communication."""
         from .parallel import allreduce_stats_tensors
+        if rows_bound is not None and 0 <= int(rows_bound) < (1 << 32):
+            self._rows_bound = int(rows_bound)  # checked against the rows counted, in check()
         (self.hist, self.histV, self.status, self.init_acc, self.nbins,
          self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
                                                self.K, self.nbins, self.tbins, group, same_extents,

@@ -59,10 +59,13 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     with the same max_count / max_total) skips the MAX all-reduce that otherwise agrees the
     extents first.
 
-    `rows_bound`: an upper bound on the rows of the whole job that EVERY rank passes alike.  Below
-    2^32 no bin can need more than 32 bits, and the message travels in 32-bit words (bins one word
-    each, the rest as (lo, hi) pairs; dme_shard_pack32 / dme_shard_unpack32): half the bytes on the
-    wire (SURVEY 8e "uint32 if N < 2^32").
+    `rows_bound`: an upper bound on the rows of the whole job that EVERY rank passes alike (ranks that
+    pass different bounds build messages of different sizes: the collective then fails or hangs).
+    Below 2^32 no bin can need more than 32 bits, and the message travels in 32-bit words (bins one
+    word each; every rank's status words and accumulators in its own slot row as (lo, hi) pairs, summed
+    in 64 bits afterwards: dme_shard_pack32 / dme_shard_unpack32): half the bytes on the wire (SURVEY
+    8e "uint32 if N < 2^32").  The promise is checked when the statistics are: DeviceStats.check()
+    raises if the job counted more rows than the bound (a bin may then have wrapped).
 
     `compact` (default: K >= COMPACT_MIN_K, or same_extents and K * nbins >= COMPACT_MIN_WORDS; the
     same on every rank): the count histograms travel as
@@ -186,7 +189,7 @@ def _sum_message(hist, histV, status, init_acc, K, group, world, rank, rows_boun
     nh, nv = hist.numel(), histV.numel()
     if rows_bound is not None and 0 <= int(rows_bound) < (1 << 32):
         if info is not None:
-            info["message_bytes"] = 4 * (nh + nv + 2 * (8 + world * (2 + K)))
+            info["message_bytes"] = 4 * (nh + nv + 2 * world * (8 + K))
         return _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank)
     nmsg = nh + nv + 8 + world * (2 + K)
     if info is not None:
@@ -226,7 +229,7 @@ def _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank):
     """The 32-bit form of the message (include/dme_hip.h, dme_shard_pack32): int32 SUM all-reduce."""
     import torch.distributed as dist
     nh, nv = hist.numel(), histV.numel()
-    nmsg = nh + nv + 2 * (8 + world * (2 + K))
+    nmsg = nh + nv + 2 * world * (8 + K)
     if hist.is_cuda:
         from . import _lib
         from .device import _on, _ptr, _stream
@@ -244,13 +247,10 @@ def _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank):
                                             _ptr(acc), _stream()))
         return out[:nh], out[nh:nh + nv], out[nh + nv:], acc
     # host tensors (gloo tests): the same message with torch
-    cap = 0xFFFFFFFF // world
-    tail = torch.zeros(8 + world * (2 + K), dtype=torch.int64)
-    tail[:8] = torch.clamp(status, max=cap)
-    tail[4:6] = 0
-    slots = tail[8:].view(world, 2 + K)
-    slots[rank, :2] = status[4:6]
-    slots[rank, 2:] = init_acc.view(torch.int64)
+    tail = torch.zeros(world * (8 + K), dtype=torch.int64)
+    slots = tail.view(world, 8 + K)
+    slots[rank, :8] = status
+    slots[rank, 8:] = init_acc.view(torch.int64)
     lohi = torch.stack([tail & 0xFFFFFFFF, (tail >> 32) & 0xFFFFFFFF], dim=1).reshape(-1)
     msg = torch.cat([hist, histV, lohi])  # int64 holding 32-bit words
     msg = (msg & 0xFFFFFFFF).to(torch.int64)
@@ -259,10 +259,10 @@ def _allreduce_words32(hist, histV, status, init_acc, K, group, world, rank):
     words = msg32.to(torch.int64) & 0xFFFFFFFF
     t = words[nh + nv:].view(-1, 2)
     tail = t[:, 0] | (t[:, 1] << 32)
-    out_status = tail[:8].clone()
-    slots = tail[8:].view(world, 2 + K)
-    out_status[4:6] = slots[:, :2].max(dim=0).values
-    parts = slots[:, 2:].contiguous().view(torch.float64)
+    slots = tail.view(world, 8 + K)
+    out_status = slots[:, :8].sum(dim=0)  # 64-bit sums of the ranks' own words: exact
+    out_status[4:6] = slots[:, 4:6].max(dim=0).values
+    parts = slots[:, 8:].contiguous().view(torch.float64)
     acc = parts[0].clone()
     for r in range(1, world):  # fixed order: bit-identical on every rank
         acc += parts[r]

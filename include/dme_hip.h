@@ -215,12 +215,16 @@ int dme_shard_unpack(uint64_t* msg /*[dev]*/, int64_t nh, int64_t nv, int64_t K,
                      double* init_acc /*[dev][K] out*/, void* stream);
 
 /* The same message in 32-bit words, for jobs of fewer than 2^32 rows in all (no bin can then exceed
- * 32 bits; SURVEY 8e "uint32 if N < 2^32"): hist | histV as one word per bin, then status[8] and the
- * slots as (lo, hi) word pairs - half the bytes on the wire.  The caller promises the row bound; the
- * additive status words are saturated at (2^32 - 1) / world per rank.  The all-reduce is an int32
- * SUM.  dme_shard_unpack32 widens the bins into hist64 / histV64 (what dme_suffix_scan reads),
- * writes status[8] with the maxima over ranks, and init_acc as dme_shard_unpack does.
- * dme_shard_message_words32 = nh + nv + 2 * (8 + world*(2 + K)). */
+ * 32 bits; SURVEY 8e "uint32 if N < 2^32"): half the bytes on the wire.
+ *     msg32 = hist[nh] | histV[nv] as one word per bin | slots[world][8 + K] as (lo, hi) word pairs
+ * A 32-bit SUM transports a 64-bit (lo, hi) pair unchanged only while one rank writes it, so a rank's
+ * eight status words ride in its own slot row in front of its K mean accumulators; every other row of
+ * its message is 0.  The all-reduce is an int32 SUM.  dme_shard_unpack32 widens the bins into hist64 /
+ * histV64 (what dme_suffix_scan reads), writes status[8] - the additive words summed over the ranks in
+ * 64 bits (exact for any split of the rows), status[4], status[5] as maxima - and init_acc as
+ * dme_shard_unpack does.  The caller promises the row bound (every rank the same one) and checks it
+ * afterwards: status[0] (the job's rows) <= the bound proves that no bin wrapped.
+ * dme_shard_message_words32 = nh + nv + 2 * world * (8 + K). */
 int64_t dme_shard_message_words32(int64_t nh, int64_t nv, int64_t K, int64_t world);
 int dme_shard_pack32(const uint64_t* hist /*[dev]*/, int64_t nh, const uint64_t* histV /*[dev]*/,
                      int64_t nv, const uint64_t* status /*[dev][8]*/,

@@ -130,6 +130,41 @@ def test_allreduce_in_32_bit_words_is_exact(world):
         assert np.array_equal(a, out[0][3])
 
 
+def _unbalanced_worker(rank, world, port, rows, out):
+    sys.path.insert(0, ROOT)
+    from bayespy_amd.parallel import allreduce_stats_tensors
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    K, nb, tb = 3, 4, 5
+    hist = torch.zeros(K * nb, dtype=torch.int64)
+    hist[1] = rows[rank]  # one bin holds every row of the shard
+    histV = torch.zeros(tb, dtype=torch.int64)
+    histV[2] = rows[rank]
+    status = torch.tensor([rows[rank], 0, 0, 0, 1 + rank, 2 + rank, 0, 0], dtype=torch.int64)
+    acc = torch.full((K,), 0.25 * (rank + 1), dtype=torch.float64)
+    res = allreduce_stats_tensors(hist, histV, status, acc, K, nb, tb, same_extents=True,
+                                  rows_bound=(1 << 32) - 1)
+    out[rank] = (res[0].numpy().copy(), res[1].numpy().copy(), res[2].numpy().copy(), res[3].numpy().copy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows", [(3_000_000_000, 1_000_000_000), (2_500_000_000, 1_000_000_000, 700_000_000)])
+def test_32_bit_message_with_unbalanced_shards(rows):
+    """A rank that holds more than 2^32 / world rows while the job stays below 2^32: every
+    rank's status words travel exactly in its own slot row and are added in 64 bits, so the row count
+    (what bench.py and DeviceStats.check() compare with the promise) and the bins are exact."""
+    world = len(rows)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_unbalanced_worker, args=(world, _free_port(), rows, out), nprocs=world, join=True)
+    for r in range(world):
+        h, v, st, a = out[r]
+        assert int(st[0]) == sum(rows) and int(h[1]) == sum(rows) and int(v[2]) == sum(rows)
+        assert int(st[4]) == world and int(st[5]) == world + 1
+        assert np.array_equal(a, out[0][3])
+
+
 @pytest.mark.parametrize("world,rows_bound", [(2, None), (3, 1000)])
 def test_allreduce_in_compact_form_is_exact(world, rows_bound):
     """compact=True: only the bins 1 .. ext[k] of every column travel (ext agreed by a MAX

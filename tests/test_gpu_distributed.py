@@ -131,7 +131,7 @@ def test_shard_message_kernels_32_bit_words(world, K, nbins, tbins):
     L = _lib.lib()
     rng = np.random.default_rng(world * 77 + K)
     nh, nv = K * nbins, tbins
-    nmsg = nh + nv + 2 * (8 + world * (2 + K))
+    nmsg = nh + nv + 2 * world * (8 + K)
     assert L.dme_shard_message_words32(nh, nv, K, world) == nmsg
     stream = torch.cuda.current_stream().cuda_stream
     total = torch.zeros(nmsg, dtype=torch.int32, device="cuda")
@@ -141,7 +141,8 @@ def test_shard_message_kernels_32_bit_words(world, K, nbins, tbins):
     for rank in range(world):
         hist = rng.integers(0, top, size=nh, dtype=np.int64)
         histV = rng.integers(0, top, size=nv, dtype=np.int64)
-        status = rng.integers(0, 1 << 28, size=8, dtype=np.int64)
+        # status words near 2^32 and beyond: the ranks' words add in 64 bits, whatever their size
+        status = rng.integers(0, 1 << 34, size=8, dtype=np.int64)
         acc = rng.random(K) * 10.0 ** rng.integers(-8, 8, size=K)
         if rank == 0:
             acc[0] = -acc[0]  # sign bit: the high word's top bit
@@ -238,6 +239,15 @@ def _nccl_one_rank(rank, port, out):
     o = ref.estimate_async(50).result()
     U, V = o["uv"].to_lists()
     res["plain"] = (U, V, o["info"]["rows"], o["alpha"], [o["n_iters"]] * 3)
+    # a row bound that the job breaks: check() says so (a bin of the 32-bit message may have wrapped)
+    low = device.DeviceStats(K, 900, int(X.sum(axis=1).max()))
+    low.add_dense(Xd, max_count=900, max_total=int(X.sum(axis=1).max()))
+    low.allreduce(force_message=True, same_extents=True, rows_bound=N - 1)
+    try:
+        low.check()
+        res["bound_error"] = ""
+    except ValueError as ex:
+        res["bound_error"] = str(ex)
     out.update(res)
     dist.destroy_process_group()
 
@@ -260,3 +270,4 @@ def test_rccl_code_path_with_one_rank():
         U, V, rows, alpha, iters = out[name]
         assert U == plain[0] and V == plain[1] and rows == plain[2], name
         assert np.array_equal(alpha, plain[3]) and iters == plain[4], name
+    assert "rows_bound" in out["bound_error"]
