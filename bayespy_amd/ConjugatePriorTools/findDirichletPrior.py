@@ -78,6 +78,10 @@ def main(argv=None, stdin=None, stdout=None):
     if Beta is None:
         # a column that is zero in every row leaves U[k] empty
         occupied = stats.hist.view(K, stats.nbins)[:, 1:].sum(dim=1)
+        cols, _, _ = stats._overflow_records()  # counts beyond the dense bins occupy a column too
+        if cols.size:
+            import torch
+            occupied[torch.from_numpy(cols).to(occupied.device)] += 1
         if bool((occupied == 0).any()):
             raise Exception(ZERO_COLUMN_MESSAGE)
 

@@ -31,8 +31,12 @@ SIGNATURES = {
     "dme_stream_create_masked": (_int, [_vp, _int, _vp]),
     "dme_stream_destroy": (_int, [_vp]),
     "dme_stats_workspace_bytes": (_i64, [_i64, _i64]),
-    "dme_stats_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
-    "dme_stats_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "dme_overflow_bytes": (_i64, [_i64]),
+    "dme_overflow_init": (_int, [_vp, _i64, _vp]),
+    "dme_overflow_extents": (_int, [_vp, _i64, _vp, _vp]),
+    "dme_overflow_append": (_int, [_vp, _vp, _vp, _vp]),
+    "dme_stats_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dme_stats_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dme_bounds_dense_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_bounds_dense_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_bounds_csr_i32": (_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
@@ -41,9 +45,11 @@ SIGNATURES = {
     "dme_dense_to_csr_u16": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dme_dense_to_csr_i32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "dme_stats_csr_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "dme_stats_csr_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64,
-                                 _vp]),
+    "dme_stats_csr_i32": (_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
+                                 _i64, _vp]),
     "dme_suffix_scan": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dme_ragged_plan": (_int, [_vp, _i64, _vp, _vp, _vp]),
+    "dme_suffix_scan_ragged": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dme_stats_dense_weighted_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dme_stats_dense_weighted_batch_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp,
                                                   _vp, _vp, _vp]),
@@ -54,8 +60,8 @@ SIGNATURES = {
     "dme_shard_unpack": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "dme_shard_extents": (_int, [_vp, _i64, _i64, _vp, _vp]),
     "dme_shard_offsets": (_int, [_vp, _i64, _vp, _vp]),
-    "dme_shard_compact": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
-    "dme_shard_expand": (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "dme_shard_compact": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "dme_shard_expand": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dme_shard_message_words32": (_i64, [_i64, _i64, _i64, _i64]),
     "dme_shard_pack32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_shard_unpack32": (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -69,6 +75,13 @@ SIGNATURES = {
     "dme_solve_enqueue": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp, _vp,
                                  _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_solve_finish": (_int, [_vp, _i64, _i64]),
+    "dme_solver_workspace_bytes_ragged": (_i64, [_i64, _i64, _i64]),
+    "dme_eval_ragged": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _f64, _int, _vp, _vp, _vp,
+                               _vp, _i64, _vp]),
+    "dme_solve_ragged": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _f64, _int, _vp,
+                                _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "dme_solve_enqueue_ragged": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _f64, _vp, _vp, _vp,
+                                        _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "dme_solve_set_path": (_int, [_int]),
     "dme_parse_count_rows": (_i64, [ctypes.c_char_p, _i64]),
     "dme_parse_counts": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _int]),
@@ -79,6 +92,16 @@ SIGNATURES = {
     "dme_synth_scratch_bytes": (_i64, [_i64]),
     "dme_synth_dirmult": (_int, [_vp, _int, _i64, _i64, _i64, _vp, _i64, _vp, _u64, _i64, _vp, _i64, _vp]),
 }
+
+
+
+class Ragged(ctypes.Structure):
+    """dme_ragged_t (include/dme_hip.h): a host struct of device pointers."""
+    _fields_ = [("offU", _vp), ("slotoff", _vp), ("slotcol", _vp), ("nslots", _i64), ("total", _i64)]
+
+
+SEGMENT_TERMS = 256  # DME_SEGMENT_TERMS
+ABI_VERSION = 2      # DME_ABI_VERSION
 
 _lib = None
 
@@ -106,7 +129,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dme_abi_version() != 1:
+        if handle.dme_abi_version() != ABI_VERSION:
             raise ImportError("libdme_hip.so ABI version mismatch")
         _lib = handle
     return _lib

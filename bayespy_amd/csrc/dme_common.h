@@ -24,6 +24,30 @@ typedef unsigned long long u64;
 typedef unsigned int u32;
 
 // ---------------------------------------------------------------------------------------------
+// Overflow store (include/dme_hip.h, dme_overflow_*): the cells of a statistics pass whose count does
+// not fit the dense histogram, hist[k][v] with v >= nbins, as records.  One outlier count then costs 16
+// bytes instead of widening every column (the reference's U[k] are lists of their own lengths,
+// DE/dme.py:118).  Layout: u64 head[2] = {used, capacity}, then `capacity` records.  `used` counts every
+// attempt, also those beyond the capacity (which the caller reports in status[1], "not counted").
+// ---------------------------------------------------------------------------------------------
+struct DmeOvfRec {
+    u32 k, v;  // column, count value
+    u64 n;     // how many rows (a statistics pass appends 1; merged stores hold sums)
+};
+static_assert(sizeof(DmeOvfRec) == 16, "record layout is part of the ABI");
+
+__device__ __forceinline__ bool dme_overflow_put(u64* ovf, u64 k, u64 v, u64 n) {
+    if (!ovf || v > 0xFFFFFFFFULL) return false;
+    const u64 i = atomicAdd(&ovf[0], 1ULL);
+    if (i >= ovf[1]) return false;
+    DmeOvfRec* r = (DmeOvfRec*)(ovf + 2) + i;
+    r->k = (u32)k;
+    r->v = (u32)v;
+    r->n = n;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wavefront (64 lanes) reductions on DPP: xor-1 / xor-2 inside a quad, then the two mirrors
 // leave every lane of a 16-lane row holding the row sum; the four row sums are combined through
 // scalar registers (v_readlane), which also makes the result wave-uniform.

@@ -33,7 +33,7 @@
 long long dme_csr2_workspace_bytes(long long N, long long nnz, long long K);
 int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, long long N, long long nnz,
                  long long K, u64* hist, long long nbins, u64* histV, long long tbins, double* init_acc,
-                 u64* status, void* workspace, long long workspace_bytes, hipStream_t s);
+                 u64* status, u64* overflow, void* workspace, long long workspace_bytes, hipStream_t s);
 
 namespace {
 
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
                                                         const int* vals, long long N, long long nnz,
                                                         long long K, u64* hist, long long nbins,
                                                         u64* histV, long long tbins, double* init_acc,
-                                                        u64* status) {
+                                                        u64* status, u64* overflow) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void stats_csr_kernel(const long long* rowptr,
             if (v < 0 || k < 0 || k >= K) { atomicAdd(&sh_stat[3], 1ULL); continue; }
             atomicMax(&sh_stat[4], (u64)v);
             if ((long long)v < nbins) atomicAdd(&hist[k * nbins + v], 1ULL);
-            else atomicAdd(&sh_stat[1], 1ULL);
+            else if (!dme_overflow_put(overflow, (u64)k, (u64)v, 1ULL)) atomicAdd(&sh_stat[1], 1ULL);
             atomicAdd(&init_acc[k], __dmul_rn((double)v, w));
         }
     }
@@ -336,6 +336,7 @@ struct CsrArgs {
     u64* histV;
     double* init_acc;
     u64* status;
+    u64* overflow;  // store for counts >= nbins (dme_common.h), or NULL
 };
 
 // LDS carve-up of csr_scatter_kernel (bytes), shared with the host for the launch size.
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(CSR_SBLOCK, 4) void csr_scatter_kernel(CsrArgs a) {
                     c[j] = (int)(((u32)k & cmask) | ((u32)x << a.sh));  // count 0: skipped downstream
                 } else {
                     if ((long long)x < a.nbins) atomicAdd(&a.hist[k * a.nbins + x], 1ULL);
-                    else big++;
+                    else if (!dme_overflow_put(a.overflow, (u64)k, (u64)x, 1ULL)) big++;
                     const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)n32[j]));
                     atomicAdd(&a.init_acc[k], __dmul_rn((double)x, w));
                 }
@@ -855,7 +856,8 @@ extern "C" int64_t dme_stats_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t
 extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, const int32_t* vals,
                                  int64_t N, int64_t nnz, int64_t K, uint64_t* hist, int64_t nbins,
                                  uint64_t* histV, int64_t tbins, double* init_acc, uint64_t* status,
-                                 void* workspace, int64_t workspace_bytes, void* stream) {
+                                 uint64_t* overflow, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
     DME_REQUIRE(N >= 0 && K >= 1 && nnz >= 0, "bad shape N=%lld K=%lld nnz=%lld", (long long)N,
                 (long long)K, (long long)nnz);
     DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
@@ -869,8 +871,8 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     bool partitioned = workspace != nullptr && nnz >= CSR_SMALL_NNZ && nnz < (1LL << 32);
     if (partitioned) {
         const int rc2 = dme_csr2_run((const long long*)rowptr, colidx, vals, N, nnz, K, (u64*)hist, nbins,
-                                     (u64*)histV, tbins, init_acc, (u64*)status, workspace,
-                                     workspace_bytes, s);
+                                     (u64*)histV, tbins, init_acc, (u64*)status, (u64*)overflow,
+                                     workspace, workspace_bytes, s);
         if (rc2 >= 0) return rc2;  // -1: more than 65 536 columns, the first design below
     }
     if (partitioned) {
@@ -888,7 +890,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
         hipLaunchKernelGGL(stats_csr_kernel, dim3((unsigned)grid), dim3(256), 0, s,
                            (const long long*)rowptr, colidx, vals, (long long)N, (long long)nnz,
                            (long long)K, (u64*)hist, (long long)nbins, (u64*)histV, (long long)tbins,
-                           init_acc, (u64*)status);
+                           init_acc, (u64*)status, (u64*)overflow);
         DME_HIP_CHECK(hipGetLastError());
         return DME_OK;
     }
@@ -919,6 +921,7 @@ extern "C" int dme_stats_csr_i32(const int64_t* rowptr, const int32_t* colidx, c
     a.TBL = (int)(tbins < CSR_TBL_MAX ? tbins : CSR_TBL_MAX);
     a.rel = rel; a.start = start; a.entries = entries;
     a.hist = (u64*)hist; a.histV = (u64*)histV; a.init_acc = init_acc; a.status = (u64*)status;
+    a.overflow = (u64*)overflow;
     const size_t lds_scatter = (size_t)scatter_lds(p.NB, a.TBL).bytes;
     DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr_scatter_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

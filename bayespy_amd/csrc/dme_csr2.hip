@@ -30,6 +30,8 @@
 // its last bits vary from run to run, as on the other CSR paths.  A malformed rowptr (negative,
 // decreasing, beyond nnz) is flagged in status[6]; such rows are not read, and rows that overlap
 // can never overrun the workspace: the chunk pool refuses allocations beyond its size.
+#include <atomic>
+
 #include "dme_common.h"
 
 namespace dme_csr2 {
@@ -145,6 +147,7 @@ struct PartArgs {
     double* init_acc;
     u64* status;
     const u32* rowptr_bad;  // set by csr3_check_kernel: the row-wise kernel below runs only then
+    u64* overflow;          // store for counts >= nbins (dme_common.h), or NULL
 };
 
 // Per-wave staging in LDS.  All of it is private to one wave: LDS serves a wave's accesses in
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(PBLOCK) void csr2_part_kernel(PartArgs a) {
             ok = false;
         }
         if (ok) maxv = (u32)v > maxv ? (u32)v : maxv;
-        if (ok && (long long)v >= a.nbins) {  // beyond the caller's histogram: reported, not counted
-            big++;                            // (the mean accumulator still takes it, as on the other paths)
+        if (ok && (long long)v >= a.nbins) {  // beyond the caller's histogram: to the overflow store, else reported
+            if (!dme_overflow_put(a.overflow, (u64)c, (u64)v, 1ULL)) big++;  // (the mean accumulator takes it anyway)
             const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
             atomicAdd(&a.init_acc[c], __dmul_rn((double)v, w));
             ok = false;
@@ -591,11 +594,11 @@ struct TileLds {
 // the row-wise kernel's `process`.  Out of line: its registers and the division stay out of the tile loop.
 // Returns 1 for a bad entry (status[3]), 2 for a count beyond the caller's histogram (status[1]), else 0.
 __device__ __noinline__ int csr3_rare_entry(u64* hist, double* init_acc, long long nbins, long long K, u32 c,
-                                            u32 v, u64 total) {
+                                            u32 v, u64 total, u64* overflow) {
     if ((int)v < 0 || c >= (u32)K) return 1;
     int r = 0;
     if ((long long)v < nbins) atomicAdd(&hist[(long long)c * nbins + v], 1ULL);
-    else r = 2;  // reported, not counted; the mean accumulator still takes it
+    else if (!dme_overflow_put(overflow, (u64)c, (u64)v, 1ULL)) r = 2;  // reported, not counted; the mean accumulator still takes it
     const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)total));
     atomicAdd(&init_acc[c], __dmul_rn((double)v, w));
     return r;
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                     if (v[i] == 0 || (ok && tot[i] < TLIM)) continue;
                     const u32 cnt = ok ? v[i] & (VLIM - 1) : v[i];
                     if ((int)cnt > 0 && c[i] < (u32)a.K) maxv = cnt > maxv ? cnt : maxv;
-                    const int r = csr3_rare_entry(a.hist, a.init_acc, a.nbins, a.K, c[i], cnt, L.RT[f[i]]);
+                    const int r = csr3_rare_entry(a.hist, a.init_acc, a.nbins, a.K, c[i], cnt, L.RT[f[i]], a.overflow);
                     if (r == 1) atomicAdd(&L.stat[3], 1ULL);
                     if (r == 2) atomicAdd(&L.stat[1], 1ULL);
                 }
@@ -1414,7 +1417,7 @@ long long dme_csr2_workspace_bytes(long long N, long long nnz, long long K) {
 // Returns DME_OK, an error, or -1 when the shape is not this design's (more than 65 536 columns).
 int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, long long N, long long nnz,
                  long long K, u64* hist, long long nbins, u64* histV, long long tbins, double* init_acc,
-                 u64* status, void* workspace, long long workspace_bytes, hipStream_t s) {
+                 u64* status, u64* overflow, void* workspace, long long workspace_bytes, hipStream_t s) {
     using namespace dme_csr2;
     Plan p;
     if (!plan(N, nnz, K, nbins, &p)) return -1;
@@ -1431,7 +1434,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     a.chunk_bucket = (unsigned char*)(ws + p.off_cbucket);
     a.chunk_fill = (unsigned short*)(ws + p.off_cfill);
     a.chunks = (u32*)(ws + p.off_chunks);
-    a.hist = hist; a.histV = histV; a.init_acc = init_acc; a.status = status;
+    a.hist = hist; a.histV = histV; a.init_acc = init_acc; a.status = status; a.overflow = overflow;
     DME_HIP_CHECK(hipMemsetAsync(a.chunk_fill, 0, 2 * p.max_chunks, s));
     // flag and rstart lie side by side: one memset
     DME_HIP_CHECK(hipMemsetAsync(ws + p.off_flag, 0, (size_t)(p.off_rstart - p.off_flag) + 8 * ((size_t)p.G3 + 1), s));
@@ -1448,10 +1451,10 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     ta.a = a;
     const size_t lds_tile = sizeof(TileLds) + 4 * (size_t)a.TB;
     const size_t lds_part = sizeof(WaveStage) * PWAVES + 4 * (size_t)a.TB;
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // zero-initialised; racing first calls both set the attribute
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr2_part_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(WaveStage) * PWAVES + 4 * TBL)));
@@ -1461,7 +1464,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)csr3_part_kernel,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(sizeof(TileLds) + 4 * TBL)));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     {
         long long cg = (N + 255) / 256;

@@ -15,19 +15,31 @@ constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_IT = 4;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_IT;
 
+// RAGGED (off != NULL): `hist` holds the bins 1 .. off[k+1] - off[k] of every column laid end to end
+// (dme_shard_compact) and U / Uf take the same places, U[k][n] at off[k] + n: a column costs its own
+// length.  slotcol (with slotoff, dme_ragged_plan) receives the column of every 256-term slot of the
+// solver's ragged layout.  Columns are dealt to the workgroups round robin (K may exceed the grid).
 __global__ __launch_bounds__(SCAN_BLOCK) void suffix_scan_kernel(
     const u64* hist, long long K, long long nbins, const u64* histV, long long tbins, long long* U,
-    double* Uf, long long ldU, long long* lenU, long long* V, double* Vf, long long* lenV) {
+    double* Uf, long long ldU, long long* lenU, long long* V, double* Vf, long long* lenV,
+    const long long* off, const long long* slotoff, int* slotcol) {
     __shared__ u64 wave_tot[SCAN_BLOCK / 64];
     __shared__ u64 wave_max[SCAN_BLOCK / 64];
-    const long long k = blockIdx.x;
-    const bool isV = k >= K;
-    const u64* src = isV ? histV : hist + k * nbins;
-    const long long nb = isV ? tbins : nbins;
-    long long* outI = isV ? V : U + k * ldU;
-    double* outF = isV ? Vf : (Uf ? Uf + k * ldU : nullptr);
-    const long long cap = isV ? tbins - 1 : ldU;  // entries available in the output row
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long long k = blockIdx.x; k <= K; k += gridDim.x) {
+    const bool isV = k >= K;
+    const long long o = (off && !isV) ? off[k] : 0;
+    const long long ext = (off && !isV) ? off[k + 1] - o : 0;
+    // src[v] = the column's bin v
+    const u64* src = isV ? histV : (off ? hist + o - 1 : hist + k * nbins);
+    const long long nb = isV ? tbins : (off ? ext + 1 : nbins);
+    long long* outI = isV ? V : (off ? U + o : U + k * ldU);
+    double* outF = isV ? Vf : (Uf ? (off ? Uf + o : Uf + k * ldU) : nullptr);
+    const long long cap = isV ? tbins - 1 : (off ? ext : ldU);  // entries available in the output row
+    if (off && !isV && slotcol) {
+        const long long s0 = slotoff[k], s1 = slotoff[k + 1];
+        for (long long i = s0 + tid; i < s1; i += SCAN_BLOCK) slotcol[i] = (int)k;
+    }
 
     u64 carry = 0;   // sum of all bins above the current tile
     u64 maxnz = 0;   // largest non-empty bin seen by this thread
@@ -86,6 +98,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void suffix_scan_kernel(
         if (isV) lenV[0] = (long long)mm;
         else lenU[k] = (long long)mm;
     }
+    __syncthreads();  // wave_max / wave_tot are reused by the workgroup's next column
+  }
 }
 
 // DE/fdp.py:104-108: priorSum = sum(priors) + 0.01; priors[i] = priors[i]/priorSum + 0.01
@@ -112,7 +126,27 @@ extern "C" int dme_suffix_scan(const uint64_t* hist, int64_t K, int64_t nbins,
     hipLaunchKernelGGL(suffix_scan_kernel, dim3((unsigned)(K + 1)), dim3(SCAN_BLOCK), 0,
                        (hipStream_t)stream, (const u64*)hist, (long long)K, (long long)nbins,
                        (const u64*)histV, (long long)tbins, (long long*)U, Uf, (long long)ldU,
-                       (long long*)lenU, (long long*)V, Vf, (long long*)lenV);
+                       (long long*)lenU, (long long*)V, Vf, (long long*)lenV, (const long long*)nullptr,
+                       (const long long*)nullptr, (int*)nullptr);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_suffix_scan_ragged(const uint64_t* compact, const int64_t* off, int64_t K,
+                                      const uint64_t* histV, int64_t tbins, int64_t* U, double* Uf,
+                                      int64_t* lenU, int64_t* V, double* Vf, int64_t* lenV,
+                                      const int64_t* slotoff, int32_t* slotcol, void* stream) {
+    DME_REQUIRE(K >= 1 && tbins >= 1, "bad shape K=%lld tbins=%lld", (long long)K, (long long)tbins);
+    DME_REQUIRE(compact && off && histV && U && lenU && V && lenV, "null pointer");
+    DME_REQUIRE((Uf == nullptr) == (Vf == nullptr), "Uf and Vf must both be given or both be NULL");
+    DME_REQUIRE((slotoff == nullptr) == (slotcol == nullptr), "slotoff and slotcol go together");
+    long long grid = K + 1;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(suffix_scan_kernel, dim3((unsigned)grid), dim3(SCAN_BLOCK), 0,
+                       (hipStream_t)stream, (const u64*)compact, (long long)K, 0LL, (const u64*)histV,
+                       (long long)tbins, (long long*)U, Uf, 0LL, (long long*)lenU, (long long*)V, Vf,
+                       (long long*)lenV, (const long long*)off, (const long long*)slotoff,
+                       (int*)slotcol);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }

@@ -175,26 +175,125 @@ __global__ __launch_bounds__(1024) void shard_offsets_kernel(const long long* ex
     if (threadIdx.x == 1023) off[K] = sh[1023];
 }
 
-// TO_COMPACT: compact[off[k] + v - 1] = hist[k][v] for v in 1 .. off[k+1] - off[k];
-// otherwise the way back: hist[k][v] = that word, and 0 in every other bin of the row.
+// TO_COMPACT: compact[off[k] + v - 1] = hist[k][v] for v in 1 .. off[k+1] - off[k] (0 beyond the dense
+// bins: those counts come from the overflow store), the words from off[K] to `capacity` are zeroed, and
+// a compact length beyond `capacity` raises status[7] (nothing is written past it).
+// Otherwise the way back: hist[k][v] = that word, and 0 in every other bin of the row; cells beyond the
+// dense bins go back to the overflow store (status[1] counts those it cannot hold).
 template <bool TO_COMPACT>
 __global__ __launch_bounds__(SHARD_BLOCK) void shard_compact_kernel(u64* hist, long long K,
                                                                     long long nbins,
                                                                     const long long* off,
-                                                                    u64* compact) {
+                                                                    u64* compact, long long capacity,
+                                                                    u64* overflow, u64* status) {
     const int lane = threadIdx.x & 63;
+    const long long total = off[K];
+    if (TO_COMPACT) {
+        const long long t = (long long)blockIdx.x * SHARD_BLOCK + threadIdx.x;
+        if (t == 0 && total > capacity && status) atomicAdd(&status[7], 1ULL);
+        for (long long i = total + t; i < capacity; i += (long long)gridDim.x * SHARD_BLOCK) compact[i] = 0ULL;
+    }
     for (long long k = (long long)blockIdx.x * COLS_PER_BLOCK + (threadIdx.x >> 6); k < K;
          k += (long long)gridDim.x * COLS_PER_BLOCK) {
         const long long o = off[k];
         const long long n = off[k + 1] - o;  // agreed over the ranks: may exceed this rank's bins
         u64* row = hist + k * nbins;
         if constexpr (TO_COMPACT) {
-            for (long long v = 1 + lane; v <= n; v += 64) compact[o + v - 1] = v < nbins ? row[v] : 0ULL;
+            for (long long v = 1 + lane; v <= n; v += 64)
+                if (o + v - 1 < capacity) compact[o + v - 1] = v < nbins ? row[v] : 0ULL;
         } else {
             for (long long v = lane; v < nbins; v += 64)
-                row[v] = (v >= 1 && v <= n) ? compact[o + v - 1] : 0ULL;
+                row[v] = (v >= 1 && v <= n && o + v - 1 < capacity) ? compact[o + v - 1] : 0ULL;
+            for (long long v = nbins + lane; v <= n; v += 64) {
+                const u64 c = o + v - 1 < capacity ? compact[o + v - 1] : 0ULL;
+                if (c && !dme_overflow_put(overflow, (u64)k, (u64)v, c) && status) atomicAdd(&status[1], c);
+            }
         }
     }
+}
+
+// ext[k] = max(ext[k], v) over the overflow records (the dense bins' extents are there already)
+__global__ __launch_bounds__(SHARD_BLOCK) void overflow_extents_kernel(const u64* overflow, long long K,
+                                                                       long long* ext) {
+    const u64 used = overflow[0] < overflow[1] ? overflow[0] : overflow[1];
+    const DmeOvfRec* rec = (const DmeOvfRec*)(overflow + 2);
+    for (u64 i = (u64)blockIdx.x * SHARD_BLOCK + threadIdx.x; i < used; i += (u64)gridDim.x * SHARD_BLOCK) {
+        const DmeOvfRec r = rec[i];
+        if (r.n && (long long)r.k < K) atomicMax((unsigned long long*)&ext[r.k], (unsigned long long)r.v);
+    }
+}
+
+// compact[off[k] + v - 1] += n for every record (after shard_compact_kernel<true> has written the dense part)
+__global__ __launch_bounds__(SHARD_BLOCK) void overflow_scatter_kernel(const u64* overflow, long long K,
+                                                                       const long long* off, u64* compact,
+                                                                       long long capacity) {
+    const u64 used = overflow[0] < overflow[1] ? overflow[0] : overflow[1];
+    const DmeOvfRec* rec = (const DmeOvfRec*)(overflow + 2);
+    for (u64 i = (u64)blockIdx.x * SHARD_BLOCK + threadIdx.x; i < used; i += (u64)gridDim.x * SHARD_BLOCK) {
+        const DmeOvfRec r = rec[i];
+        if (!r.n || (long long)r.k >= K || r.v == 0) continue;
+        const long long o = off[r.k], n = off[r.k + 1] - o;
+        if ((long long)r.v <= n && o + r.v - 1 < capacity) atomicAdd(&compact[o + r.v - 1], r.n);
+    }
+}
+
+// dst gets src's records appended (merging two stores)
+__global__ __launch_bounds__(SHARD_BLOCK) void overflow_append_kernel(u64* dst, const u64* src, u64* status) {
+    const u64 used = src[0] < src[1] ? src[0] : src[1];
+    const DmeOvfRec* rec = (const DmeOvfRec*)(src + 2);
+    for (u64 i = (u64)blockIdx.x * SHARD_BLOCK + threadIdx.x; i < used; i += (u64)gridDim.x * SHARD_BLOCK) {
+        const DmeOvfRec r = rec[i];
+        if (r.n && !dme_overflow_put(dst, r.k, r.v, r.n) && status) atomicAdd(&status[1], r.n);
+    }
+}
+
+__global__ void overflow_init_kernel(u64* store, u64 capacity) {
+    store[0] = 0;
+    store[1] = capacity;
+}
+
+// The ragged layout's two offset tables in one launch (one workgroup, as shard_offsets_kernel):
+// off[k] = ext[0] + ... + ext[k-1] and slotoff[k] = the same over ceil(ext / seg), both with K + 1 entries.
+__global__ __launch_bounds__(1024) void ragged_plan_kernel(const long long* ext, long long K, long long seg,
+                                                           long long* off, long long* slotoff) {
+    __shared__ long long sh[2][1024];
+    const long long per = (K + 1023) / 1024;
+    const long long lo = (long long)threadIdx.x * per, hi = lo + per < K ? lo + per : K;
+    long long s = 0, q = 0;
+    for (long long k = lo; k < hi; ++k) {
+        const long long e = ext[k] > 0 ? ext[k] : 0;
+        s += e;
+        q += (e + seg - 1) / seg;
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long a0 = threadIdx.x >= d ? sh[0][threadIdx.x - d] : 0;
+        const long long a1 = threadIdx.x >= d ? sh[1][threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[0][threadIdx.x] += a0;
+        sh[1][threadIdx.x] += a1;
+        __syncthreads();
+    }
+    long long run = sh[0][threadIdx.x] - s, qrun = sh[1][threadIdx.x] - q;  // exclusive
+    for (long long k = lo; k < hi; ++k) {
+        const long long e = ext[k] > 0 ? ext[k] : 0;
+        off[k] = run;
+        slotoff[k] = qrun;
+        run += e;
+        qrun += (e + seg - 1) / seg;
+    }
+    if (threadIdx.x == 1023) {
+        off[K] = sh[0][1023];
+        slotoff[K] = sh[1][1023];
+    }
+}
+
+long long overflow_grid(long long n) {
+    long long g = (n + SHARD_BLOCK - 1) / SHARD_BLOCK;
+    if (g > 1024) g = 1024;
+    return g < 1 ? 1 : g;
 }
 
 long long shard_col_grid(long long K) {
@@ -223,22 +322,68 @@ extern "C" int dme_shard_offsets(const int64_t* ext, int64_t K, int64_t* off, vo
     return DME_OK;
 }
 
-extern "C" int dme_shard_compact(const uint64_t* hist, int64_t K, int64_t nbins, const int64_t* off,
-                                 uint64_t* compact, void* stream) {
-    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1, "bad arguments");
+extern "C" int dme_shard_compact(const uint64_t* hist, int64_t K, int64_t nbins,
+                                 const uint64_t* overflow, const int64_t* off, uint64_t* compact,
+                                 int64_t capacity, uint64_t* status, void* stream) {
+    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1 && capacity >= 0, "bad arguments");
     hipLaunchKernelGGL(shard_compact_kernel<true>, dim3((unsigned)shard_col_grid(K)),
                        dim3(SHARD_BLOCK), 0, (hipStream_t)stream, (u64*)hist, (long long)K,
-                       (long long)nbins, (const long long*)off, (u64*)compact);
+                       (long long)nbins, (const long long*)off, (u64*)compact, (long long)capacity,
+                       (u64*)nullptr, (u64*)status);
+    if (overflow)
+        hipLaunchKernelGGL(overflow_scatter_kernel, dim3(256), dim3(SHARD_BLOCK), 0, (hipStream_t)stream,
+                           (const u64*)overflow, (long long)K, (const long long*)off, (u64*)compact,
+                           (long long)capacity);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }
 
-extern "C" int dme_shard_expand(const uint64_t* compact, int64_t K, int64_t nbins,
-                                const int64_t* off, uint64_t* hist, void* stream) {
-    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1, "bad arguments");
+extern "C" int dme_shard_expand(const uint64_t* compact, int64_t capacity, int64_t K, int64_t nbins,
+                                const int64_t* off, uint64_t* hist, uint64_t* overflow,
+                                uint64_t* status, void* stream) {
+    DME_REQUIRE(hist && off && compact && K >= 1 && nbins >= 1 && capacity >= 0, "bad arguments");
     hipLaunchKernelGGL(shard_compact_kernel<false>, dim3((unsigned)shard_col_grid(K)),
                        dim3(SHARD_BLOCK), 0, (hipStream_t)stream, (u64*)hist, (long long)K,
-                       (long long)nbins, (const long long*)off, (u64*)compact);
+                       (long long)nbins, (const long long*)off, (u64*)compact, (long long)capacity,
+                       (u64*)overflow, (u64*)status);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int64_t dme_overflow_bytes(int64_t capacity) {
+    if (capacity < 0 || capacity > (1LL << 40)) return -1;
+    return 16 + 16 * capacity;
+}
+
+extern "C" int dme_overflow_init(uint64_t* store, int64_t capacity, void* stream) {
+    DME_REQUIRE(store && capacity >= 0 && ((uintptr_t)store % 16) == 0, "bad overflow store");
+    hipLaunchKernelGGL(overflow_init_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (u64*)store,
+                       (u64)capacity);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_overflow_extents(const uint64_t* overflow, int64_t K, int64_t* ext, void* stream) {
+    DME_REQUIRE(overflow && ext && K >= 1, "bad arguments");
+    hipLaunchKernelGGL(overflow_extents_kernel, dim3(256), dim3(SHARD_BLOCK), 0, (hipStream_t)stream,
+                       (const u64*)overflow, (long long)K, (long long*)ext);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_overflow_append(uint64_t* dst, const uint64_t* src, uint64_t* status, void* stream) {
+    DME_REQUIRE(dst && src && dst != src, "bad arguments");
+    hipLaunchKernelGGL(overflow_append_kernel, dim3(256), dim3(SHARD_BLOCK), 0, (hipStream_t)stream,
+                       (u64*)dst, (const u64*)src, (u64*)status);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_ragged_plan(const int64_t* ext, int64_t K, int64_t* off, int64_t* slotoff,
+                               void* stream) {
+    DME_REQUIRE(ext && off && slotoff && K >= 1, "bad arguments");
+    hipLaunchKernelGGL(ragged_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       (const long long*)ext, (long long)K, 256LL, (long long*)off, (long long*)slotoff);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }

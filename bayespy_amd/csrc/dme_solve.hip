@@ -24,11 +24,14 @@
 
 #include <mutex>
 
+#include <atomic>
+
 #include "dme_common.h"
 
 namespace {
 
 constexpr int SEG = 256;         // terms per segment: 4 per lane
+static_assert(SEG == DME_SEGMENT_TERMS, "dme_ragged_plan (dme_shard.hip) cuts columns into slots of this size");
 #ifndef DME_STEP_BLOCK
 #define DME_STEP_BLOCK 512  // 1024-thread single-workgroup kernels measured 2x slower per launch
 #endif
@@ -141,7 +144,9 @@ __host__ __device__ inline long long slots_per_column(long long ld) {
     return n < 1 ? 1 : n;
 }
 
-Ws carve(void* base, long long K, long long ldU, long long capV) {
+// nU: the slots of the K columns - K * slots_per_column(ldU) for dense-padded U, the ragged layout's own
+// count otherwise.
+Ws carve(void* base, long long K, long long nU, long long capV) {
     Ws w{};
     long long off = 0;
     char* b = (char*)base;
@@ -150,7 +155,7 @@ Ws carve(void* base, long long K, long long ldU, long long capV) {
         off += align256(bytes);
         return p;
     };
-    w.nseg_max = K * slots_per_column(ldU) + slots_per_column(capV);
+    w.nseg_max = nU + slots_per_column(capV);
     w.ctrl = (Ctrl*)take(sizeof(Ctrl));
     w.part = (Partial*)take(w.nseg_max * (long long)sizeof(Partial));
     w.alpha_cur = (double*)take(K * 8);
@@ -309,7 +314,30 @@ struct EvalArgs {  // the statistics as the entry points receive them
     const double* Vf;
     long long capV;
     const long long* lenV;
+    // RAGGED layout (offU != NULL; include/dme_hip.h, dme_ragged_t): column k's terms start at
+    // Uf[offU[k]] and it owns the slots [slotoff[k], slotoff[k + 1]); slotcol[s] names the column of
+    // slot s.  A column then takes the memory and the slots of its own length, not of the longest
+    // column's (DE/dme.py:118: the reference's U[k] are lists of their own lengths).
+    const long long* offU;
+    const long long* slotoff;
+    const int* slotcol;
+    long long nslotsU;
 };
+
+// slots of the K columns (V's slots follow them)
+__device__ __forceinline__ long long eval_nslots_u(const EvalArgs& e, long long K, long long S) {
+    return e.offU ? e.nslotsU : K * S;
+}
+// first slot of column k
+__device__ __forceinline__ long long eval_slot_base(const EvalArgs& e, long long k, long long S) {
+    return e.offU ? e.slotoff[k] : k * S;
+}
+// len(U[k]), clamped to the column's allocation
+__device__ __forceinline__ long long eval_col_len(const EvalArgs& e, long long k) {
+    const long long L = e.lenU[k];
+    const long long cap = e.offU ? e.offU[k + 1] - e.offU[k] : e.ldU;
+    return L > cap ? cap : L;
+}
 
 // What a wave can load for its first segment before the trial point is known (iter_kernel issues
 // these loads at kernel start, beside the loads of the state): the column's length and the wave's
@@ -322,14 +350,23 @@ struct EvalPrefetch {
 __device__ __forceinline__ void eval_slot_of(const EvalArgs& e, long long K, long long S, long long s,
                                              long long& k, long long& st, const double*& u,
                                              long long& cap) {
-    if (s < K * S) {
-        k = s / S;
-        st = (s - k * S) * SEG;
-        u = e.Uf + k * e.ldU;
-        cap = e.ldU;
+    const long long nU = eval_nslots_u(e, K, S);
+    if (s < nU) {
+        if (e.offU) {
+            k = e.slotcol[s];
+            st = (s - e.slotoff[k]) * SEG;
+            const long long o = e.offU[k];
+            u = e.Uf + o;
+            cap = e.offU[k + 1] - o;
+        } else {
+            k = s / S;
+            st = (s - k * S) * SEG;
+            u = e.Uf + k * e.ldU;
+            cap = e.ldU;
+        }
     } else {
         k = K;
-        st = (s - K * S) * SEG;
+        st = (s - nU) * SEG;
         u = e.Vf;
         cap = e.capV;
     }
@@ -363,7 +400,7 @@ __device__ __forceinline__ void eval_segments(const Ctrl* ctrl, const EvalArgs& 
     if (ctrl->done || !ctrl->trial_valid) return;
     const int lane = threadIdx.x & 63;
     const long long S = slots_per_column(e.ldU);
-    const long long nslots = K * S + slots_per_column(e.capV);
+    const long long nslots = eval_nslots_u(e, K, S) + slots_per_column(e.capV);
     for (long long s = wave0; s < nslots; s += nwaves) {
         long long k, st, cap;
         const double* u;
@@ -472,16 +509,15 @@ __device__ __forceinline__ void gather_prefetch(const EvalArgs& e, const Partial
     pf.pv = PartV{{0, 0, 0, 0, 0}};
     // up to 64 slots: every wave holds them all, one per lane (gather_eval sums them inside the wave)
     const long long vslot = SV <= 64 ? (long long)(tid & 63) : (long long)tid;
-    if (vslot < SV) pf.pv = ld_part(part + K * S + vslot);
+    if (vslot < SV) pf.pv = ld_part(part + eval_nslots_u(e, K, S) + vslot);
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
         const long long k = tid + (long long)c * STEP_BLOCK;
         pf.L[c] = 0;
         pf.p[c] = PartV{{0, 0, 0, 0, 0}};
         if (k < K) {
-            long long L = e.lenU[k];
-            pf.L[c] = L > e.ldU ? e.ldU : L;
-            pf.p[c] = ld_part(part + k * S);
+            pf.L[c] = eval_col_len(e, k);
+            pf.p[c] = ld_part(part + eval_slot_base(e, k, S));
         }
     }
 }
@@ -506,6 +542,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
     Gathered G;
     const int tid = threadIdx.x;
     const long long S = slots_per_column(e.ldU);
+    const long long nU = eval_nslots_u(e, K, S);
     // V = column K
     {
         long long LV;
@@ -527,7 +564,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
             PartV p{{0, 0, 0, 0, 0}};
             if (lane < nv) {
                 if constexpr (NCOL > 0) p = pf->pv;
-                else p = ld_part(w.part + K * S + lane);
+                else p = ld_part(w.part + nU + lane);
             }
             a[0] = dme_wave_sum_acc(DmeAcc{p.v[0], p.v[1]});
             a[1] = dme_wave_sum_acc(DmeAcc{p.v[2], p.v[3]});
@@ -536,7 +573,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
             for (long long i = tid; i < nv; i += STEP_BLOCK) {
                 PartV p;
                 if constexpr (NCOL > 0) p = pf->pv;  // SV <= STEP_BLOCK: i == tid
-                else p = ld_part(w.part + K * S + i);
+                else p = ld_part(w.part + nU + i);
                 a[0].add(DmeAcc{p.v[0], p.v[1]});
                 a[1].add(DmeAcc{p.v[2], p.v[3]});
                 d[0] = __dadd_rn(d[0], p.v[4]);
@@ -595,18 +632,17 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
                 const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
                 DmeAcc a0{0, 0}, a1{0, 0};
                 double a2 = 0.0;
-                if (cnt > 0) gather_slots(w.part + k * S, 1, cnt, &pf->p[c], a0, a1, a2);
+                if (cnt > 0) gather_slots(w.part + eval_slot_base(e, k, S), 1, cnt, &pf->p[c], a0, a1, a2);
                 column(k, a0, a1, a2);
             }
         }
     } else {
         for (long long k = tid; k < K; k += STEP_BLOCK) {
-            long long L = e.lenU[k];
-            if (L > e.ldU) L = e.ldU;
+            const long long L = eval_col_len(e, k);
             const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
             DmeAcc a0{0, 0}, a1{0, 0};
             double a2 = 0.0;
-            gather_slots(w.part + k * S, 0, cnt, nullptr, a0, a1, a2);
+            gather_slots(w.part + eval_slot_base(e, k, S), 0, cnt, nullptr, a0, a1, a2);
             column(k, a0, a1, a2);
         }
     }
@@ -1053,7 +1089,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void iter_kernel(Ws w, EvalArgs e, Prio
     double* l_dcur = kvec + 2 * K;
     double* l_atr = kvec + 3 * K;
     const long long wave0 = (long long)blockIdx.x * STEP_WAVES + (tid >> 6);
-    const long long nslots = K * slots_per_column(e.ldU) + slots_per_column(e.capV);
+    const long long nslots = eval_nslots_u(e, K, slots_per_column(e.ldU)) + slots_per_column(e.capV);
 
     // ---- one round of loads: this wave's first segment, this thread's partial sums, the state -----
     EvalPrefetch epf;
@@ -1195,15 +1231,35 @@ __global__ __launch_bounds__(STEP_BLOCK) void predicted_step_kernel(double hcons
     if (threadIdx.x == 0) status[0] = ok ? 0 : DME_ERR_ZERO_DIVISION;
 }
 
-int check_common(const double* Uf, long long ldU, const long long* lenU, const double* Vf,
-                 long long capV, const long long* lenV, long long K, void* workspace,
-                 long long workspace_bytes, Ws* w) {
+// the slots of the K columns: dense-padded U gives every column those of the longest one
+long long host_nslots_u(const EvalArgs& e, long long K) {
+    return e.offU ? e.nslotsU : K * slots_per_column(e.ldU);
+}
+
+EvalArgs dense_args(const double* Uf, long long ldU, const long long* lenU, const double* Vf,
+                    long long capV, const long long* lenV) {
+    return EvalArgs{Uf, ldU, lenU, Vf, capV, lenV, nullptr, nullptr, nullptr, 0};
+}
+
+// dme_ragged_t -> EvalArgs (ldU: the longest column's allocation is not known here and not needed; the
+// slot count stands in for it where a number identifies the shape)
+int ragged_args(const double* Uf, const dme_ragged_t* rg, const long long* lenU, const double* Vf,
+                long long capV, const long long* lenV, EvalArgs* out) {
+    DME_REQUIRE(rg != nullptr && rg->offU && rg->slotoff && rg->slotcol, "null ragged layout");
+    DME_REQUIRE(rg->nslots >= 0 && rg->nslots < (1LL << 31) && rg->total >= 0, "bad ragged layout");
+    *out = EvalArgs{Uf, rg->nslots > 0 ? rg->nslots : 1, lenU, Vf, capV, lenV, (const long long*)rg->offU,
+                    (const long long*)rg->slotoff, (const int*)rg->slotcol, (long long)rg->nslots};
+    return DME_OK;
+}
+
+int check_common(const EvalArgs& e, long long K, void* workspace, long long workspace_bytes, Ws* w) {
+    const long long ldU = e.ldU, capV = e.capV;
     DME_REQUIRE(K >= 1 && ldU >= 1 && capV >= 1, "bad shape K=%lld ldU=%lld capV=%lld", K, ldU, capV);
     DME_REQUIRE(K < (1LL << 31) && ldU < (1LL << 31) && capV < (1LL << 31), "shape too large");
-    DME_REQUIRE(Uf && lenU && Vf && lenV, "null statistics pointer");
+    DME_REQUIRE(e.Uf && e.lenU && e.Vf && e.lenV, "null statistics pointer");
     DME_REQUIRE(workspace != nullptr && ((uintptr_t)workspace % 256) == 0,
                 "workspace must be a 256-byte aligned device pointer");
-    *w = carve(workspace, K, ldU, capV);
+    *w = carve(workspace, K, host_nslots_u(e, K), capV);
     if (workspace_bytes < w->bytes)
         return dme_set_error(DME_ERR_WORKSPACE, "solver workspace: need %lld bytes, got %lld",
                              w->bytes, workspace_bytes);
@@ -1236,19 +1292,25 @@ unsigned eval_grid(long long nseg_max) {
 
 extern "C" int64_t dme_solver_workspace_bytes(int64_t K, int64_t ldU, int64_t capV) {
     if (K < 1 || ldU < 1 || capV < 1) return -1;
-    return carve(nullptr, K, ldU, capV).bytes;
+    return carve(nullptr, K, K * slots_per_column(ldU), capV).bytes;
+}
+
+extern "C" int64_t dme_solver_workspace_bytes_ragged(int64_t K, int64_t nslots, int64_t capV) {
+    if (K < 1 || nslots < 0 || capV < 1) return -1;
+    return carve(nullptr, K, nslots, capV).bytes;
 }
 
 namespace {
 
-int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf, int64_t capV,
-              const int64_t* lenV, int64_t K, const double* alpha, Prior pr, double* out_scalars,
+int eval_impl(const EvalArgs& ea, int64_t K, const double* alpha, Prior pr, double* out_scalars,
               double* out_grad, double* out_hdiag, void* workspace, int64_t workspace_bytes,
               void* stream) {
     Ws w;
-    int rc = check_common(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K,
-                          workspace, workspace_bytes, &w);
+    int rc = check_common(ea, K, workspace, workspace_bytes, &w);
     if (rc) return rc;
+    const long long* lenU = ea.lenU;
+    const long long* lenV = ea.lenV;
+    const long long ldU = ea.ldU, capV = ea.capV;
     DME_REQUIRE(alpha && out_scalars, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, alpha, (long long)K,
@@ -1256,8 +1318,6 @@ int eval_impl(const double* Uf, int64_t ldU, const int64_t* lenU, const double* 
                        (long long)ldU, (long long)capV, (long long*)nullptr, (const double*)nullptr,
                        (const u64*)nullptr);
     // the evaluation itself ignores the positivity test (dirichLogProb has none); force it on
-    const EvalArgs ea{Uf, (long long)ldU, (const long long*)lenU, Vf, (long long)capV,
-                      (const long long*)lenV};
     hipLaunchKernelGGL(eval_kernel, dim3(eval_grid(w.nseg_max)), dim3(EVAL_BLOCK), 0, s,
                        (const Ctrl*)w.ctrl, ea, (long long)K, (const double*)w.alpha_trial, w.part);
     const bool cpt = pr.beta != nullptr || pr.has_W;
@@ -1278,8 +1338,8 @@ extern "C" int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, cons
                         double hyperprior, double* out_scalars, double* out_grad,
                         double* out_hdiag, void* workspace, int64_t workspace_bytes, void* stream) {
     const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
-    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
-                     workspace, workspace_bytes, stream);
+    return eval_impl(dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                     alpha, pr, out_scalars, out_grad, out_hdiag, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
@@ -1288,8 +1348,22 @@ extern "C" int dme_eval_cpt(const double* Uf, int64_t ldU, const int64_t* lenU, 
                             double* out_grad, double* out_hdiag, void* workspace,
                             int64_t workspace_bytes, void* stream) {
     const Prior pr{0.0, beta, W, has_W ? 1 : 0, 0};
-    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
-                     workspace, workspace_bytes, stream);
+    return eval_impl(dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                     alpha, pr, out_scalars, out_grad, out_hdiag, workspace, workspace_bytes, stream);
+}
+
+// dme_eval / dme_eval_cpt on the ragged layout (beta == NULL and has_W == 0: the scalar hyperprior).
+extern "C" int dme_eval_ragged(const double* Uf, const dme_ragged_t* ragged, const int64_t* lenU,
+                               const double* Vf, int64_t capV, const int64_t* lenV, int64_t K,
+                               const double* alpha, double hyperprior, const double* beta, double W,
+                               int has_W, double* out_scalars, double* out_grad, double* out_hdiag,
+                               void* workspace, int64_t workspace_bytes, void* stream) {
+    EvalArgs ea;
+    int rc = ragged_args(Uf, ragged, (const long long*)lenU, Vf, capV, (const long long*)lenV, &ea);
+    if (rc) return rc;
+    DME_REQUIRE(!(hyperprior != 0.0 && (beta || has_W)), "the scalar hyperprior and (Beta, W) do not combine");
+    const Prior pr{hyperprior, beta, W, has_W ? 1 : 0, 0};
+    return eval_impl(ea, K, alpha, pr, out_scalars, out_grad, out_hdiag, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,24 +1383,30 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
 namespace {
 
 constexpr int kMaxDevices = 64;
-void* g_scratch_ptr[kMaxDevices] = {};
+std::atomic<void*> g_scratch_ptr[kMaxDevices];  // zero-initialised
 std::mutex g_scratch_mutex;
 
-// Device address of `scratch` on the current device (looked up on the first call per device).
+// Device address of `scratch` on the current device.  Looked up on the first call per device (under a
+// mutex; hipGetSymbolAddress may load the code object there, which is not a capturable stream
+// operation: that first call must be made eagerly, outside any HIP graph capture); every later call
+// is one atomic load.
 int noalloc_scratch(void** out) {
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
     if (dev < 0 || dev >= kMaxDevices)
         return dme_set_error(DME_ERR_UNSUPPORTED, "device ordinal %d beyond %d", dev, kMaxDevices);
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch_ptr[dev]) {
-        void* p = nullptr;
-        DME_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        if (!p || ((uintptr_t)p % 256) != 0)
-            return dme_set_error(DME_ERR_HIP, "hipGetSymbolAddress(scratch) returned %p", p);
-        g_scratch_ptr[dev] = p;
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!p) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (!p) {
+            DME_HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            if (!p || ((uintptr_t)p % 256) != 0)
+                return dme_set_error(DME_ERR_HIP, "hipGetSymbolAddress(scratch) returned %p", p);
+            g_scratch_ptr[dev].store(p, std::memory_order_release);
+        }
     }
-    *out = g_scratch_ptr[dev];
+    *out = p;
     return DME_OK;
 }
 
@@ -1339,7 +1419,7 @@ extern "C" int dme_eval_noalloc(const double* Uf, int64_t ldU, const int64_t* le
     DME_REQUIRE(K >= 1 && ldU >= 1 && capV >= 1, "bad shape K=%lld ldU=%lld capV=%lld",
                 (long long)K, (long long)ldU, (long long)capV);
     DME_REQUIRE(K < (1LL << 31) && ldU < (1LL << 31) && capV < (1LL << 31), "shape too large");
-    const long long need = carve(nullptr, K, ldU, capV).bytes;
+    const long long need = carve(nullptr, K, K * slots_per_column(ldU), capV).bytes;
     if (need > kNoAllocScratchBytes)
         return dme_set_error(DME_ERR_WORKSPACE,
                              "dme_eval_noalloc: K=%lld ldU=%lld capV=%lld needs %lld bytes of solver "
@@ -1350,8 +1430,8 @@ extern "C" int dme_eval_noalloc(const double* Uf, int64_t ldU, const int64_t* le
     int rc = noalloc_scratch(&ws);
     if (rc) return rc;
     const Prior pr{hyperprior, nullptr, 0.0, 0, 0};
-    return eval_impl(Uf, ldU, lenU, Vf, capV, lenV, K, alpha, pr, out_scalars, out_grad, out_hdiag,
-                     ws, kNoAllocScratchBytes, stream);
+    return eval_impl(dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                     alpha, pr, out_scalars, out_grad, out_hdiag, ws, kNoAllocScratchBytes, stream);
 }
 
 extern "C" int dme_predicted_step(double hconst, const double* hdiag, const double* grad, int64_t K,
@@ -1388,12 +1468,7 @@ namespace {
 
 // Everything a solve needs besides the workspace: the arguments of dme_solve / dme_solve_enqueue.
 struct SolveCall {
-    const double* Uf;
-    long long ldU;
-    const long long* lenU;
-    const double* Vf;
-    long long capV;
-    const long long* lenV;
+    EvalArgs ea;
     long long K;
     double* alpha;
     long long iterations;
@@ -1423,13 +1498,13 @@ template <bool CPT, int NCOL>
 int launch_iter(const Ws& w, const EvalArgs& ea, const Prior& pr, const IterArgs& a, unsigned grid,
                 size_t lds, hipStream_t s) {
     auto kern = iter_kernel<CPT, NCOL>;
-    static bool attr_set[64] = {};  // per instantiation and device
+    static std::atomic<bool> attr_set[64];  // zero-initialised; racing first calls both set the attribute  // per instantiation and device
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)(6 * FUSED_KMAX * 8)));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(STEP_BLOCK), lds, s, w, ea, pr, a);
     return DME_OK;
@@ -1454,10 +1529,10 @@ int launch_iter_ncol(int ncol, const Ws& w, const EvalArgs& ea, const Prior& pr,
 int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first, long long count,
                      hipStream_t s) {
     const bool cpt = c.pr.beta != nullptr || c.pr.has_W;
-    const EvalArgs ea{c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV};
+    const EvalArgs& ea = c.ea;
     if (first == 0 && path != DME_SOLVE_PATH_FUSED) {
         hipLaunchKernelGGL(setup_kernel, dim3(1), dim3(STEP_BLOCK), 0, s, w, (const double*)c.alpha,
-                           c.K, (long long)PH_INIT, c.lenU, c.lenV, c.ldU, c.capV, c.result,
+                           c.K, (long long)PH_INIT, ea.lenU, ea.lenV, ea.ldU, ea.capV, c.result,
                            c.init_acc, c.status);
         DME_HIP_CHECK(hipGetLastError());
     }
@@ -1483,7 +1558,7 @@ int enqueue_launches(const SolveCall& c, const Ws& w, int path, long long first,
         if (fg < 1) fg = 1;
         // the gathered partial sums are prefetched when a thread's share is small and fixed
         int ncol = 0;
-        if (slots_per_column(c.ldU) <= PF_SMAX && slots_per_column(c.capV) <= STEP_BLOCK)
+        if (!ea.offU && slots_per_column(ea.ldU) <= PF_SMAX && slots_per_column(ea.capV) <= STEP_BLOCK)
             ncol = c.K <= STEP_BLOCK ? 1 : (c.K <= 2 * STEP_BLOCK ? 2 : 4);
         for (long long j = first; j < first + count; ++j) {
             const IterArgs a{c.K, c.iterations, c.trace, c.trace_alpha, c.trace_cap, c.alpha, c.result,
@@ -1559,7 +1634,7 @@ int result_error(const long long* res) {
 int solve_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_t workspace_bytes,
                void* stream) {
     Ws w;
-    int rc = check_common(c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K, workspace, workspace_bytes, &w);
+    int rc = check_common(c.ea, c.K, workspace, workspace_bytes, &w);
     if (rc) return rc;
     if ((rc = check_call(c))) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -1567,7 +1642,7 @@ int solve_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_
     const long long limit = max_launches(c.iterations);
     long long* pinned = poll_buffer();
     if (!pinned) return dme_set_error(DME_ERR_HIP, "hipHostMalloc of the poll buffer failed");
-    long long launched = 0, batch = first_batch(c.K, c.ldU, path), done = 0;
+    long long launched = 0, batch = first_batch(c.K, c.ea.ldU, path), done = 0;
     while (!done) {
         if ((rc = enqueue_launches(c, w, path, launched, batch, s))) return rc;
         launched += batch;
@@ -1579,7 +1654,7 @@ int solve_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_
             return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", launched);
         batch = launched < 64 ? 8 : 32;
     }
-    remember_solve(c.K, c.ldU, pinned[4]);  // evaluations' worth of launches that did work
+    remember_solve(c.K, c.ea.ldU, pinned[4]);  // evaluations' worth of launches that did work
     if (result_host)
         for (int i = 0; i < 8; ++i) result_host[i] = pinned[i];
     return result_error(pinned);
@@ -1593,8 +1668,8 @@ extern "C" int dme_solve(const double* Uf, int64_t ldU, const int64_t* lenU, con
                          int64_t trace_cap, int64_t* result, int64_t* result_host,
                          double* final_loss, void* workspace, int64_t workspace_bytes,
                          void* stream) {
-    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
-                      iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, nullptr, nullptr, trace,
+    const SolveCall c{dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                      alpha, iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, nullptr, nullptr, trace,
                       trace_alpha, trace_cap, (long long*)result, final_loss};
     return solve_impl(c, result_host, workspace, workspace_bytes, stream);
 }
@@ -1606,11 +1681,57 @@ extern "C" int dme_solve_cpt(const double* Uf, int64_t ldU, const int64_t* lenU,
                              int64_t* result_host, double* final_loss, void* workspace,
                              int64_t workspace_bytes, void* stream) {
     // inside findDirichletPriors the loss carries no prior term (CPT/dme.py:109-110)
-    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
-                      iterations, Prior{0.0, beta, W, has_W ? 1 : 0, 1}, nullptr, nullptr, trace,
+    const SolveCall c{dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                      alpha, iterations, Prior{0.0, beta, W, has_W ? 1 : 0, 1}, nullptr, nullptr, trace,
                       trace_alpha, trace_cap, (long long*)result, final_loss};
     return solve_impl(c, result_host, workspace, workspace_bytes, stream);
 }
+
+// dme_solve / dme_solve_cpt on the ragged layout (beta == NULL and has_W == 0: the scalar hyperprior).
+extern "C" int dme_solve_ragged(const double* Uf, const dme_ragged_t* ragged, const int64_t* lenU,
+                                const double* Vf, int64_t capV, const int64_t* lenV, int64_t K,
+                                double* alpha, int64_t iterations, double hyperprior,
+                                const double* beta, double W, int has_W, double* trace,
+                                double* trace_alpha, int64_t trace_cap, int64_t* result,
+                                int64_t* result_host, double* final_loss, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    EvalArgs ea;
+    int rc = ragged_args(Uf, ragged, (const long long*)lenU, Vf, capV, (const long long*)lenV, &ea);
+    if (rc) return rc;
+    const bool cpt = beta != nullptr || has_W;
+    DME_REQUIRE(!(hyperprior != 0.0 && cpt), "the scalar hyperprior and (Beta, W) do not combine");
+    const SolveCall c{ea, K, alpha, iterations, Prior{hyperprior, beta, W, has_W ? 1 : 0, cpt ? 1 : 0},
+                      nullptr, nullptr, trace, trace_alpha, trace_cap, (long long*)result, final_loss};
+    return solve_impl(c, result_host, workspace, workspace_bytes, stream);
+}
+
+namespace {
+
+int enqueue_impl(const SolveCall& c, int64_t* result_host, void* workspace, int64_t workspace_bytes,
+                 int64_t first, int64_t count, int64_t* enqueued, void* stream) {
+    Ws w;
+    int rc = check_common(c.ea, c.K, workspace, workspace_bytes, &w);
+    if (rc) return rc;
+    if ((rc = check_call(c))) return rc;
+    DME_REQUIRE(first >= 0 && count >= 0 && result_host && enqueued, "bad first / count / null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int path = pick_path(c.K, w.nseg_max);
+    if (first > max_launches(c.iterations))
+        return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", (long long)first);
+    if (path == DME_SOLVE_PATH_SINGLE && first > 0) {
+        // the single launch runs the whole loop and always sets `done`: asking for more launches means
+        // its result was lost, and enqueueing nothing while reporting launches would loop the caller
+        *enqueued = 0;
+        return dme_set_error(DME_ERR_INTERNAL, "the single-launch solver takes no further launches");
+    }
+    if (count == 0) count = first == 0 ? first_batch(c.K, c.ea.ldU, path) : (first < 64 ? 8 : 32);
+    if ((rc = enqueue_launches(c, w, path, first, count, s))) return rc;
+    *enqueued = count;
+    DME_HIP_CHECK(hipMemcpyAsync(result_host, c.result, 16 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    return DME_OK;
+}
+
+}  // namespace
 
 extern "C" int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
                                  int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
@@ -1619,23 +1740,27 @@ extern "C" int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* l
                                  int64_t trace_cap, int64_t* result, int64_t* result_host,
                                  void* workspace, int64_t workspace_bytes, int64_t first,
                                  int64_t count, int64_t* enqueued, void* stream) {
-    const SolveCall c{Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV, K, alpha,
-                      iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, init_acc, (const u64*)status,
-                      trace, trace_alpha, trace_cap, (long long*)result, nullptr};
-    Ws w;
-    int rc = check_common(c.Uf, c.ldU, c.lenU, c.Vf, c.capV, c.lenV, c.K, workspace, workspace_bytes, &w);
+    const SolveCall c{dense_args(Uf, ldU, (const long long*)lenU, Vf, capV, (const long long*)lenV), K,
+                      alpha, iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, init_acc,
+                      (const u64*)status, trace, trace_alpha, trace_cap, (long long*)result, nullptr};
+    return enqueue_impl(c, result_host, workspace, workspace_bytes, first, count, enqueued, stream);
+}
+
+// dme_solve_enqueue on the ragged layout; dme_solve_finish(result_host, K, ragged->nslots) afterwards.
+extern "C" int dme_solve_enqueue_ragged(const double* Uf, const dme_ragged_t* ragged,
+                                        const int64_t* lenU, const double* Vf, int64_t capV,
+                                        const int64_t* lenV, int64_t K, double* alpha,
+                                        int64_t iterations, double hyperprior, const double* init_acc,
+                                        const uint64_t* status, double* trace, double* trace_alpha,
+                                        int64_t trace_cap, int64_t* result, int64_t* result_host,
+                                        void* workspace, int64_t workspace_bytes, int64_t first,
+                                        int64_t count, int64_t* enqueued, void* stream) {
+    EvalArgs ea;
+    int rc = ragged_args(Uf, ragged, (const long long*)lenU, Vf, capV, (const long long*)lenV, &ea);
     if (rc) return rc;
-    if ((rc = check_call(c))) return rc;
-    DME_REQUIRE(first >= 0 && count >= 0 && result_host && enqueued, "bad first / count / null pointer");
-    hipStream_t s = (hipStream_t)stream;
-    const int path = pick_path(K, w.nseg_max);
-    if (first > max_launches(iterations))
-        return dme_set_error(DME_ERR_INTERNAL, "solver did not finish after %lld launches", (long long)first);
-    if (count == 0) count = first == 0 ? first_batch(K, ldU, path) : (first < 64 ? 8 : 32);
-    if ((rc = enqueue_launches(c, w, path, first, count, s))) return rc;
-    *enqueued = count;
-    DME_HIP_CHECK(hipMemcpyAsync(result_host, result, 16 * sizeof(long long), hipMemcpyDeviceToHost, s));
-    return DME_OK;
+    const SolveCall c{ea, K, alpha, iterations, Prior{hyperprior, nullptr, 0.0, 0, 0}, init_acc,
+                      (const u64*)status, trace, trace_alpha, trace_cap, (long long*)result, nullptr};
+    return enqueue_impl(c, result_host, workspace, workspace_bytes, first, count, enqueued, stream);
 }
 
 extern "C" int dme_solve_finish(const int64_t* result_host, int64_t K, int64_t ldU) {

@@ -25,6 +25,8 @@
 
 #include <type_traits>
 
+#include <atomic>
+
 #include "dme_common.h"
 
 namespace {
@@ -60,6 +62,7 @@ struct StatsArgs {
     int CL;        // side-by-side rows: lanes per row = ceil(C / J); lane c of a row holds the vectors
                    // c, c + CL, ... of it
     int tail;      // K % E when the rows end inside a vector (then K >= E), else 0
+    u64* overflow;  // store for cells with v >= nbins (dme_common.h), or NULL: such cells are reported in status[1]
 };
 
 // Compile-time ablation switches for timing experiments (never set in the shipped build):
@@ -239,7 +242,8 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     for (int i = tid; i < nwords; i += BLOCK) lds[i] = 0;
     // Data-error counters and the maxima seen by the rare global-atomic paths live in LDS, not in
     // registers (the maxima of the LDS-privatised bins are taken by hist_reduce_kernel):
-    // [1] cells >= nbins, [2] rows >= tbins, [3] negative cells, [4] max count, [5] max row total.
+    // [1] cells >= nbins, [2] rows >= tbins, [3] negative cells, [4] max count, [5] max row total,
+    // [7] team waits that timed out (an internal fault: the result is incomplete).
     __shared__ u64 sh_stat[8];
     __shared__ u64 sh_tot[2][TW > 1 ? W : 1][RB];  // teams: the waves' partial row totals
     __shared__ u32 sh_team[TW > 1 ? WR : 1];        // teams: parts published so far
@@ -491,9 +495,19 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 team_target += TW;
+                // Bounded (MI355X_MICROARCH.md: bound every spin): a mate that never arrives - only
+                // an edit that lets one wave of a team leave the loop early could cause it - ends the
+                // wait after ~2^22 sleeps (seconds) and raises status[7]: the pass then reports
+                // itself incomplete instead of hanging the CU.
+                u32 spins = 0;
                 while (__hip_atomic_load(&sh_team[wrow], __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_WORKGROUP) < team_target)
+                                         __HIP_MEMORY_SCOPE_WORKGROUP) < team_target) {
                     __builtin_amdgcn_s_sleep(1);
+                    if (__builtin_expect(++spins > (1u << 22), 0)) {
+                        if (lane == 0) atomicAdd(&sh_stat[7], 1ULL);
+                        break;
+                    }
+                }
                 asm volatile("" ::: "memory");
             } else {
                 if (lane == 0) {
@@ -587,10 +601,10 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                     b.d[rb][j][e] = 0;
                                 } else if (v > 0xFFFF) {
                                     atomicMax(&sh_stat[4], (u64)v);
+                                    const long long k = (long long)opaque(chunk) * E + e;
                                     if ((long long)v < nbins) {
-                                        const long long k = (long long)opaque(chunk) * E + e;
                                         atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    } else {
+                                    } else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL)) {
                                         atomicAdd(&sh_stat[1], 1ULL);
                                     }
                                     acc[j][e] = mean_add(acc[j][e], (double)v, w);
@@ -621,7 +635,8 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                                                 : (long long)opaque(chunk) * E + 2 * q + h;
                                     atomicMax(&sh_stat[4], (u64)v);
                                     if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    else atomicAdd(&sh_stat[1], 1ULL);
+                                    else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL))
+                                        atomicAdd(&sh_stat[1], 1ULL);
                                     acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, wv[(2 * q + h) / KC % SUB]);
                                     dwl[q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
                                 }
@@ -688,10 +703,10 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                 b.d[rb][j][e] = 0;
                             } else if (v > B) {
                                 atomicMax(&sh_stat[4], (u64)v);
+                                const long long k = (long long)opaque(chunk) * E + e;
                                 if ((long long)v < nbins) {
-                                    const long long k = (long long)opaque(chunk) * E + e;
                                     atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                } else {
+                                } else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL)) {
                                     atomicAdd(&sh_stat[1], 1ULL);
                                 }
                                 acc[j][e] = mean_add(acc[j][e], (double)v, w);
@@ -793,6 +808,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     if (tid == 0) atomicAdd(&a.status[0], (u64)SUB * (inter ? (blockIdx.x == 0 ? (u64)a.N : 0ULL) : (u64)nrows));
     if (tid >= 1 && tid <= 3 && sh_stat[tid]) atomicAdd(&a.status[tid], sh_stat[tid]);
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
+    if (tid == 7 && sh_stat[7]) atomicAdd(&a.status[7], sh_stat[7]);  // a team wait that timed out
 }
 
 constexpr int RED_SLICES = 16;  // interleaved slices of workgroups per output (threadIdx.y)
@@ -962,6 +978,7 @@ struct PairArgs {
     long long tbins;
     double* init_acc;
     u64* status;
+    u64* overflow;
 };
 
 constexpr int PAIR_BLOCK = 1024, PAIR_RB = 4;
@@ -986,7 +1003,7 @@ __device__ __noinline__ void pair_odd_row(const PairArgs& a, u32 x0, u32 x1, u64
         if (v == 0) continue;
         atomicMax(&sh_stat[4], (u64)v);
         if ((long long)v < a.nbins) atomicAdd(&a.hist[(long long)k * a.nbins + v], 1ULL);
-        else atomicAdd(&sh_stat[1], 1ULL);
+        else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL)) atomicAdd(&sh_stat[1], 1ULL);
         atomicAdd(&a.init_acc[k], __dmul_rn((double)v, w));
     }
     atomicMax(&sh_stat[5], (u64)total);
@@ -1140,7 +1157,7 @@ __global__ __launch_bounds__(1024) void pair_marginals_kernel(PairArgs a) {
 
 // Returns DME_OK, an error, or -1 when the shape is not this pass's (too many bins, workspace).
 int stats_pair_run(const void* X, bool i32, long long NV, u64* hist, long long nbins, u64* histV,
-                   long long tbins, double* init_acc, u64* status, void* workspace,
+                   long long tbins, double* init_acc, u64* status, u64* overflow, void* workspace,
                    long long workspace_bytes, hipStream_t s) {
     if (nbins < 2 || nbins > 1024) return -1;
     const long long ncell = nbins * nbins;
@@ -1170,16 +1187,16 @@ int stats_pair_run(const void* X, bool i32, long long NV, u64* hist, long long n
     a.pairs = (u64*)((char*)workspace + img_bytes);
     a.G = G;
     a.steps = (NV + G * per - 1) / (G * per);
-    a.hist = hist; a.nbins = nbins; a.histV = histV; a.tbins = tbins; a.init_acc = init_acc; a.status = status;
-    static bool attr_set[64] = {};
+    a.hist = hist; a.nbins = nbins; a.histV = histV; a.tbins = tbins; a.init_acc = init_acc; a.status = status; a.overflow = overflow;
+    static std::atomic<bool> attr_set[64];  // zero-initialised; racing first calls both set the attribute
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel<false>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes + 1024));
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)stats_pair_kernel<true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kPairLdsBytes + 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     if (i32)
         hipLaunchKernelGGL(stats_pair_kernel<true>, dim3((unsigned)G), dim3(PAIR_BLOCK), (size_t)(a.part_words * 4), s, a);
@@ -1429,13 +1446,13 @@ template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bo
 int launch_dense_t(const StatsArgs& a, const Plan& p, hipStream_t s) {
     auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];  // zero-initialised; racing first calls both set the attribute
     int dev = 0;
     DME_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         DME_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kLdsBudgetBytes + 1024));
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(p.block), p.lds_bytes, s, a);
     DME_HIP_CHECK(hipGetLastError());
@@ -1504,7 +1521,7 @@ int dispatch_team(const StatsArgs& a, const Plan& p, hipStream_t s) {
 
 template <typename T>
 int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
-                    u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
+                    u64* histV, long long tbins, double* init_acc, u64* status, u64* overflow, void* workspace,
                     long long workspace_bytes, void* stream, bool padded) {
     // uint16 rows of 2 or 4 columns back to back: whole rows inside 16-byte vectors, the few rows
     // that do not fill a vector afterwards on their own
@@ -1516,12 +1533,12 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     if (!padded && K == 2 && ld == 2 && ((uintptr_t)X % 16) == 0 && N >= kSubMinRows) {
         const long long rpv = 16 / (2 * (long long)sizeof(T));  // rows per vector
         int rc = stats_pair_run(X, sizeof(T) == 4, N / rpv, hist, nbins, histV, tbins, init_acc,
-                                status, workspace, workspace_bytes, (hipStream_t)stream);
+                                status, overflow, workspace, workspace_bytes, (hipStream_t)stream);
         if (rc > 0) return rc;
         if (rc == DME_OK) {
             if (N % rpv)
                 return stats_dense_run<T>(X + (N / rpv) * rpv * 2, N % rpv, K, ld, hist, nbins, histV, tbins,
-                                          init_acc, status, workspace, workspace_bytes, stream, false);
+                                          init_acc, status, overflow, workspace, workspace_bytes, stream, false);
             return DME_OK;
         }
     }
@@ -1538,7 +1555,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     DME_REQUIRE(((uintptr_t)workspace % 16) == 0, "workspace must be 16-byte aligned");
     u32* hist_part = (u32*)((char*)workspace + init_bytes);
     StatsArgs a{X, N, K, sub > 1 ? 8LL : ld, hist, nbins, histV, tbins, (double*)workspace, hist_part,
-                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC, p.CL, p.tail};
+                p.part_words, status, p.rows_per_wg, p.C, p.R, p.B, p.BRW, p.TB, p.TBpad, p.VC, p.Vw, p.WT, p.hoff, p.CW, p.steps, p.adjacent, p.RC, p.CL, p.tail, overflow};
     hipStream_t s = (hipStream_t)stream;
     constexpr int EMAX = 16 / (int)sizeof(T);
     if (p.TW > 1) {
@@ -1614,7 +1631,7 @@ int stats_dense_run(const T* X, long long N, long long K, long long ld, u64* his
     DME_HIP_CHECK(hipGetLastError());
     if (sub > 1 && Nall > N * sub)
         return stats_dense_run<T>(X + N * sub * K, Nall - N * sub, K, ld, hist, nbins, histV, tbins,
-                                  init_acc, status, workspace, workspace_bytes, stream, false);
+                                  init_acc, status, overflow, workspace, workspace_bytes, stream, false);
     return DME_OK;
 }
 
@@ -1629,7 +1646,7 @@ long long base_workspace_bytes(long long N, long long K) {
 
 template <typename T>
 int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, long long nbins,
-                u64* histV, long long tbins, double* init_acc, u64* status, void* workspace,
+                u64* histV, long long tbins, double* init_acc, u64* status, u64* overflow, void* workspace,
                 long long workspace_bytes, void* stream) {
     DME_REQUIRE(N >= 0 && K >= 1 && ld >= K, "bad shape N=%lld K=%lld ld=%lld", N, K, ld);
     DME_REQUIRE(nbins >= 1 && tbins >= 1, "nbins/tbins must be >= 1");
@@ -1637,8 +1654,8 @@ int stats_dense(const T* X, long long N, long long K, long long ld, u64* hist, l
     DME_REQUIRE(K * nbins < (1LL << 40), "hist too large");
     if (N == 0) return DME_OK;
     DME_REQUIRE(X != nullptr, "X is null");
-    return stats_dense_run<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status, workspace,
-                              workspace_bytes, stream, false);
+    return stats_dense_run<T>(X, N, K, ld, hist, nbins, histV, tbins, init_acc, status, overflow,
+                              workspace, workspace_bytes, stream, false);
 }
 
 }  // namespace
@@ -1655,19 +1672,19 @@ extern "C" int64_t dme_stats_workspace_bytes(int64_t N, int64_t K) {
 
 extern "C" int dme_stats_dense_u16(const uint16_t* X, int64_t N, int64_t K, int64_t ld,
                                    uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
-                                   double* init_acc, uint64_t* status, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   double* init_acc, uint64_t* status, uint64_t* overflow,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     return stats_dense<unsigned short>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
-                                       (u64*)status, workspace, workspace_bytes, stream);
+                                       (u64*)status, (u64*)overflow, workspace, workspace_bytes, stream);
 }
 
 #endif
 #if DME_STATS_PART != 0
 extern "C" int dme_stats_dense_i32(const int32_t* X, int64_t N, int64_t K, int64_t ld,
                                    uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
-                                   double* init_acc, uint64_t* status, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+                                   double* init_acc, uint64_t* status, uint64_t* overflow,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     return stats_dense<int>(X, N, K, ld, (u64*)hist, nbins, (u64*)histV, tbins, init_acc,
-                            (u64*)status, workspace, workspace_bytes, stream);
+                            (u64*)status, (u64*)overflow, workspace, workspace_bytes, stream);
 }
 #endif

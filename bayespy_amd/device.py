@@ -19,8 +19,18 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._trace import phase as _phase
 
 TRACE_CAP = 4096  # iterations whose trace (loss, gradient size, branch, alphas) is kept
+
+# The count histograms are dense K x nbins only up to DENSE_CELLS cells (256 MB of 64-bit bins): nbins
+# stops at max(DENSE_MIN_BINS, DENSE_CELLS // K) and larger counts are records of an overflow store
+# (include/dme_hip.h).  From RAGGED_MIN_CELLS cells on - or whenever a store is in use - finalize()
+# lays U/V out ragged, every column at its own length, as the reference's lists are (DE/dme.py:118).
+DENSE_CELLS = 1 << 25
+DENSE_MIN_BINS = 64
+RAGGED_MIN_CELLS = 1 << 22
+OVERFLOW_CAPACITY = 1 << 16  # records of a first overflow store (1 MB); see DeviceStats.overflow_capacity
 
 EXIT_MESSAGES = {
     1: "Converged with small gradient",    # DE/dme.py:146
@@ -74,10 +84,17 @@ def _ptr(t):
 
 
 class DeviceUV:
-    """The reference's compressed statistics on the device: dense-padded fp64 U (K x ldU),
-    lenU[K], V, lenV — what every solver entry point consumes."""
+    """The reference's compressed statistics on the device — what every solver entry point consumes.
 
-    def __init__(self, K, Uf, ldU, lenU, Vf, lenV, U=None, V=None):
+    Two layouts of the fp64 U (and of its exact int64 twin `Ui`):
+      dense-padded  K x ldU, U[k][n] at k * ldU + n (zero padding is neutral in every sum);
+      ragged        every column at its own length, U[k][n] at off[k] + n (`ragged` holds the offset and
+                    slot tables of include/dme_hip.h, dme_ragged_t) — the reference's lists are ragged
+                    too (DE/dme.py:118), and one outlier count then costs one long column, not K of
+                    them.
+    lenU[K], V, lenV are the same in both."""
+
+    def __init__(self, K, Uf, ldU, lenU, Vf, lenV, U=None, V=None, ragged=None):
         self.K = int(K)
         self.Uf, self.ldU, self.lenU = Uf, int(ldU), lenU
         self.Vf, self.lenV = Vf, lenV
@@ -85,6 +102,23 @@ class DeviceUV:
         self.Ui, self.Vi = U, V  # exact int64 copies when built by the scan
         self.device = Uf.device
         self._ws = None
+        # ragged layout: (off[K+1], slotoff[K+1], slotcol[nslots], nslots, total) - device tensors and
+        # two host integers; self._rg is the C struct handed to the *_ragged entries
+        self.ragged = ragged
+        self._rg = None
+        if ragged is not None:
+            off, slotoff, slotcol, nslots, total = ragged
+            self._rg = _lib.Ragged(off.data_ptr(), slotoff.data_ptr(), slotcol.data_ptr(), int(nslots),
+                                   int(total))
+            self.nslots = int(nslots)
+
+    @property
+    def shape_key(self):
+        """What dme_solve_finish files the launch-count hint under (ldU, or the ragged slot count)."""
+        return self.nslots if self.ragged is not None else self.ldU
+
+    def _rgp(self):
+        return ctypes.addressof(self._rg)
 
     # -- construction from host-side ragged lists (foreign data objects with .U/.V) ------------
     @classmethod
@@ -92,24 +126,45 @@ class DeviceUV:
         device = require_gpu(device)
         K = len(U)
         ldU = max(1, max((len(u) for u in U), default=0))
-        host = np.zeros((K, ldU), dtype=np.float64)
-        lenU = np.zeros(K, dtype=np.int64)
-        for k, u in enumerate(U):
-            n = len(u)
-            lenU[k] = n
-            if n:
-                host[k, :n] = np.asarray(u, dtype=np.float64)
         capV = max(1, len(V))
         vhost = np.zeros(capV, dtype=np.float64)
         if len(V):
             vhost[:len(V)] = np.asarray(V, dtype=np.float64)
+        lenU = np.array([len(u) for u in U], dtype=np.int64)
+        lenV = torch.tensor([len(V)], dtype=torch.int64, device=device)
+        if K * ldU >= RAGGED_MIN_CELLS and int(lenU.sum()) * 2 < K * ldU:
+            # long lists of very different lengths: kept ragged, as they arrive
+            seg = _lib.SEGMENT_TERMS
+            off = np.zeros(K + 1, dtype=np.int64)
+            np.cumsum(lenU, out=off[1:])
+            cnt = (lenU + seg - 1) // seg
+            slotoff = np.zeros(K + 1, dtype=np.int64)
+            np.cumsum(cnt, out=slotoff[1:])
+            total, nslots = int(off[K]), int(slotoff[K])
+            host = np.zeros(max(total, 1), dtype=np.float64)
+            for k, u in enumerate(U):
+                if len(u):
+                    host[off[k]:off[k + 1]] = np.asarray(u, dtype=np.float64)
+            slotcol = np.repeat(np.arange(K, dtype=np.int32), cnt)
+            if nslots == 0:
+                slotcol = np.zeros(1, dtype=np.int32)
+            rg = (torch.from_numpy(off).to(device), torch.from_numpy(slotoff).to(device),
+                  torch.from_numpy(slotcol).to(device), nslots, total)
+            return cls(K, torch.from_numpy(host).to(device), 1, torch.from_numpy(lenU).to(device),
+                       torch.from_numpy(vhost).to(device), lenV, ragged=rg)
+        host = np.zeros((K, ldU), dtype=np.float64)
+        for k, u in enumerate(U):
+            if len(u):
+                host[k, :len(u)] = np.asarray(u, dtype=np.float64)
         return cls(K, torch.from_numpy(host).to(device), ldU, torch.from_numpy(lenU).to(device),
-                   torch.from_numpy(vhost).to(device),
-                   torch.tensor([len(V)], dtype=torch.int64, device=device))
+                   torch.from_numpy(vhost).to(device), lenV)
 
     def workspace(self):
         if self._ws is None:
-            nbytes = _lib.lib().dme_solver_workspace_bytes(self.K, self.ldU, self.capV)
+            if self.ragged is not None:
+                nbytes = _lib.lib().dme_solver_workspace_bytes_ragged(self.K, self.nslots, self.capV)
+            else:
+                nbytes = _lib.lib().dme_solver_workspace_bytes(self.K, self.ldU, self.capV)
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self._ws.data_ptr()) % 256
         return self._ws.data_ptr() + off, self._ws.numel() - off
@@ -118,17 +173,36 @@ class DeviceUV:
         """(U, V) as the reference holds them: ragged lists of ints."""
         lenU = self.lenU.cpu().numpy()
         lenV = int(self.lenV.cpu()[0])
-        if self.Ui is not None:
-            Uh = self.Ui.view(self.K, self.ldU).cpu().numpy()
-            Vh = self.Vi.cpu().numpy()
-            U = [[int(x) for x in Uh[k, :lenU[k]]] for k in range(self.K)]
-            V = [int(x) for x in Vh[:lenV]]
+        exact = self.Ui is not None
+        Uh = (self.Ui if exact else self.Uf).cpu().numpy()
+        Vh = (self.Vi if exact else self.Vf).cpu().numpy()
+        if self.ragged is not None:
+            off = self.ragged[0].cpu().numpy()
+            rows = [Uh[off[k]:off[k] + lenU[k]] for k in range(self.K)]
         else:
-            Uh = self.Uf.view(self.K, self.ldU).cpu().numpy()
-            Vh = self.Vf.cpu().numpy()
-            U = [Uh[k, :lenU[k]].tolist() for k in range(self.K)]
-            V = Vh[:lenV].tolist()
-        return U, V
+            Uh = Uh.reshape(self.K, self.ldU)
+            rows = [Uh[k, :lenU[k]] for k in range(self.K)]
+        if exact:
+            return [[int(x) for x in r] for r in rows], [int(x) for x in Vh[:lenV]]
+        return [r.tolist() for r in rows], Vh[:lenV].tolist()
+
+    def dense_U(self):
+        """The exact U as a dense K x max(len) int64 tensor on the device, whatever the layout (tests
+        and checks; a torch scatter, off the hot path)."""
+        if self.Ui is None:
+            raise ValueError("no exact integer U (weighted statistics)")
+        if self.ragged is None:
+            return self.Ui.view(self.K, self.ldU)
+        off = self.ragged[0]
+        ext = off[1:] - off[:-1]
+        width = max(int(ext.max()), 1)
+        out = torch.zeros(self.K, width, dtype=torch.int64, device=self.device)
+        total = int(off[self.K])
+        if total:
+            col = torch.repeat_interleave(torch.arange(self.K, device=self.device), ext)
+            pos = torch.arange(total, device=self.device) - off[:-1][col]
+            out[col, pos] = self.Ui[:total]
+        return out
 
     # -- one evaluation: loss, gradient, Hessian parts (DE/dme.py:16-61) -------------------------
     def _beta(self, Beta):
@@ -150,19 +224,26 @@ class DeviceUV:
             grad = torch.empty(self.K, dtype=torch.float64, device=self.device)
             hdiag = torch.empty(self.K, dtype=torch.float64, device=self.device)
             ws, wsb = self.workspace()
-            if Beta is None and W is None:
+            cpt = not (Beta is None and W is None)
+            if cpt and hyperprior:
+                raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
+            b = self._beta(Beta) if cpt else None
+            w, has_w = (0.0 if W is None else float(W)), (0 if W is None else 1)
+            if self.ragged is not None:
+                _lib.check(_lib.lib().dme_eval_ragged(
+                    _ptr(self.Uf), self._rgp(), _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), float(hyperprior), _ptr(b), w, has_w, _ptr(scal),
+                    _ptr(grad), _ptr(hdiag), ws, wsb, _stream()))
+            elif not cpt:
                 _lib.check(_lib.lib().dme_eval(
                     _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
                     _ptr(self.lenV), self.K, _ptr(a), float(hyperprior), _ptr(scal), _ptr(grad),
                     _ptr(hdiag), ws, wsb, _stream()))
             else:
-                if hyperprior:
-                    raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
-                b = self._beta(Beta)
                 _lib.check(_lib.lib().dme_eval_cpt(
                     _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
-                    _ptr(self.lenV), self.K, _ptr(a), _ptr(b), 0.0 if W is None else float(W),
-                    0 if W is None else 1, _ptr(scal), _ptr(grad), _ptr(hdiag), ws, wsb, _stream()))
+                    _ptr(self.lenV), self.K, _ptr(a), _ptr(b), w, has_w, _ptr(scal), _ptr(grad),
+                    _ptr(hdiag), ws, wsb, _stream()))
             s = scal.cpu().numpy()
             return float(s[0]), float(s[1]), grad.cpu().numpy(), hdiag.cpu().numpy(), float(s[3])
 
@@ -175,7 +256,7 @@ class DeviceUV:
         `consume_init`: a float64 device tensor passed as init_alphas is overwritten with the result
         instead of being copied first (the caller gives it up; saves a device copy)."""
         iterations = int(iterations)
-        with _on(self.device):
+        with _on(self.device), _phase("solve"):
             if (consume_init and isinstance(init_alphas, torch.Tensor)
                     and init_alphas.device == self.device and init_alphas.dtype == torch.float64
                     and init_alphas.is_contiguous()):
@@ -198,20 +279,27 @@ class DeviceUV:
                       if trace_alphas else None)
             host = (ctypes.c_int64 * 8)()
             ws, wsb = self.workspace()
-            if Beta is None and W is None:
+            cpt = not (Beta is None and W is None)
+            if cpt and hyperprior:
+                raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
+            b = self._beta(Beta) if cpt else None
+            w, has_w = (0.0 if W is None else float(W)), (0 if W is None else 1)
+            if self.ragged is not None:
+                _lib.check(_lib.lib().dme_solve_ragged(
+                    _ptr(self.Uf), self._rgp(), _ptr(self.lenU), _ptr(self.Vf), self.capV,
+                    _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(b), w, has_w,
+                    _ptr(trace), _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss),
+                    ws, wsb, _stream()))
+            elif not cpt:
                 _lib.check(_lib.lib().dme_solve(
                     _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
                     _ptr(self.lenV), self.K, _ptr(a), iterations, float(hyperprior), _ptr(trace),
                     _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
                     _stream()))
             else:
-                if hyperprior:
-                    raise ValueError("the scalar hyperprior and (Beta, W) do not combine")
-                b = self._beta(Beta)
                 _lib.check(_lib.lib().dme_solve_cpt(
                     _ptr(self.Uf), self.ldU, _ptr(self.lenU), _ptr(self.Vf), self.capV,
-                    _ptr(self.lenV), self.K, _ptr(a), iterations, _ptr(b),
-                    0.0 if W is None else float(W), 0 if W is None else 1, _ptr(trace),
+                    _ptr(self.lenV), self.K, _ptr(a), iterations, _ptr(b), w, has_w, _ptr(trace),
                     _ptr(talpha), cap, _ptr(result), ctypes.addressof(host), _ptr(floss), ws, wsb,
                     _stream()))
             # dme_solve synchronised the stream and filled `host`: no further device round trip
@@ -257,10 +345,20 @@ class DeviceStats:
     mean accumulator.  Row chunks and row shards (GPUs) simply add, so `allreduce()` is one integer
     sum; `finalize()` runs the reverse suffix scan that yields the reference's U/V."""
 
-    def __init__(self, K, max_count=1, max_total=1, device=None):
+    def __init__(self, K, max_count=1, max_total=1, device=None, dense_bins=None,
+                 overflow_capacity=OVERFLOW_CAPACITY):
+        """dense_bins: the widest dense count histogram (bins per column, bin 0 included; default
+        max(64, 2^25 // K)); counts beyond it are records of the overflow store, which holds
+        `overflow_capacity` of them (a full store reports the cells it had to drop: check() raises)."""
         self.device = require_gpu(device)
         self.K = int(K)
-        self.nbins = max(int(max_count), 1) + 1
+        self.dense_bins = (int(dense_bins) if dense_bins is not None
+                           else max(DENSE_MIN_BINS, DENSE_CELLS // max(self.K, 1)))
+        if self.dense_bins < 2:
+            raise ValueError("dense_bins must be at least 2")
+        self.overflow_capacity = int(overflow_capacity)
+        self.overflow = None  # int64 tensor [2 + 2 * capacity]: head + records (dme_overflow_*)
+        self.nbins = min(max(int(max_count), 1) + 1, self.dense_bins)
         self.tbins = max(int(max_total), 1) + 1
         with _on(self.device):
             # one zero-filled buffer (one memset): hist | histV | status | init_acc (fp64 zeros are
@@ -273,26 +371,39 @@ class DeviceStats:
             self.init_acc = buf[nh + nv + 8:].view(torch.float64)
         self._ws = None
         self._csr_ws = None
+        if int(max_count) + 1 > self.dense_bins:
+            self._need_overflow()
+
+    def _need_overflow(self):
+        if self.overflow is None:
+            L = _lib.lib()
+            cap = max(self.overflow_capacity, 1)
+            with _on(self.device):
+                self.overflow = torch.empty(L.dme_overflow_bytes(cap) // 8, dtype=torch.int64,
+                                            device=self.device)
+                _lib.check(L.dme_overflow_init(_ptr(self.overflow), cap, _stream()))
 
     # -- capacity -------------------------------------------------------------------------------
     def reserve(self, max_count, max_total):
-        """Grow the histograms so that counts <= max_count and totals <= max_total fit."""
-        nb = max(self.nbins, int(max_count) + 1)
+        """Grow the histograms so that counts <= max_count and totals <= max_total fit: the dense
+        bins up to `dense_bins`, an overflow store for larger counts."""
+        want = max(self.nbins, int(max_count) + 1)
+        nb = min(want, max(self.dense_bins, self.nbins))
         tb = max(self.tbins, int(max_total) + 1)
+        if want > nb:
+            self._need_overflow()
         if nb != self.nbins:
-            # The statistics are kept as K x (max_count + 1) cells: 8 bytes each here and 16 more in
-            # finalize() (integer and fp64 U).  One outlier count sets the width for every column.
-            need = 8 * self.K * nb + 8 * self.K * self.nbins
-            whole = 24 * self.K * nb
-            free = torch.cuda.mem_get_info(self.device)[0]
-            if self.K * nb >= (1 << 40) or need > free:
+            if self.K * nb >= (1 << 40):
+                raise MemoryError(f"statistics for K={self.K} columns x {nb} dense bins exceed 2^40 cells")
+            try:
+                new = torch.zeros(self.K, nb, dtype=torch.int64, device=self.device)
+            except torch.cuda.OutOfMemoryError as e:
+                # (asking the allocator, not mem_get_info: blocks torch holds cached count as free)
                 raise MemoryError(
-                    f"statistics for K={self.K} columns with counts up to max_count={nb - 1} take "
-                    f"{whole / 2**30:.1f} GiB on the device (24 bytes x K x (max_count + 1); "
-                    f"{free / 2**30:.1f} GiB are free): the histograms are dense per column, so a "
-                    f"single very large count widens all of them.  Clip or split such rows, or "
-                    f"estimate the heavy columns separately.")
-            new = torch.zeros(self.K, nb, dtype=torch.int64, device=self.device)
+                    f"statistics for K={self.K} columns with {nb} dense count bins take "
+                    f"{8 * self.K * nb / 2**30:.1f} GiB on the device, which it does not have; pass a "
+                    f"smaller dense_bins to DeviceStats (larger counts then go to the overflow store)"
+                ) from e
             new[:, :self.nbins] = self.hist.view(self.K, self.nbins)
             self.hist, self.nbins = new.view(-1), nb
         if tb != self.tbins:
@@ -342,11 +453,11 @@ class DeviceStats:
             max_count = mc if max_count is None else max_count
             max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
-        with _on(self.device):
+        with _on(self.device), _phase("stats"):
             ws, wsb = self._workspace(X.shape[0], X)
             rc = fn(X.data_ptr(), X.shape[0], self.K, X.stride(0), _ptr(self.hist),
                     self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc),
-                    _ptr(self.status), ws, wsb, _stream())
+                    _ptr(self.status), _ptr(self.overflow), ws, wsb, _stream())
             if rc == _lib.ERR_UNSUPPORTED:
                 # rows wider than the dense kernels take (uint16: 32 768 columns, int32: 16 384)
                 return self._add_dense_as_csr(X, max_count, max_total)
@@ -400,7 +511,7 @@ class DeviceStats:
             max_total = mt if max_total is None else max_total
         self.reserve(max_count, max_total)
         nnz = colidx.numel()
-        with _on(self.device):
+        with _on(self.device), _phase("stats"):
             need = _lib.lib().dme_stats_csr_workspace_bytes(N, nnz, self.K)
             ws, wsb = 0, 0
             if need > 0:
@@ -412,7 +523,7 @@ class DeviceStats:
             _lib.check(_lib.lib().dme_stats_csr_i32(
                 _ptr(rowptr), _ptr(colidx), _ptr(vals), N, nnz, self.K, _ptr(self.hist),
                 self.nbins, _ptr(self.histV), self.tbins, _ptr(self.init_acc), _ptr(self.status),
-                ws, wsb, _stream()))
+                _ptr(self.overflow), ws, wsb, _stream()))
         return self
 
     def check_async(self):
@@ -443,8 +554,18 @@ class DeviceStats:
         if st[6]:
             raise ValueError("CSR input inconsistent: rowptr is negative, decreasing, or spans more "
                              "entries than colidx / vals hold")
+        if st[7]:
+            raise _lib.DmeError(
+                f"{int(st[7])} internal faults in the statistics pass or its all-reduce (a bounded "
+                "in-kernel wait expired, or a compact message outgrew the compact_bound promised to "
+                "allreduce()): the statistics are incomplete")
         if st[3]:
             raise ValueError(f"{int(st[3])} negative counts (or column indices out of range)")
+        if st[1] and self.overflow is not None:
+            raise ValueError(
+                f"statistics incomplete: the overflow store ({self.overflow_capacity} records) could not "
+                f"hold {int(st[1])} cells with a count >= {self.nbins} (largest seen: {int(st[4])}); "
+                "pass a larger overflow_capacity or dense_bins to DeviceStats")
         if st[1] or st[2]:
             raise ValueError(
                 f"statistics incomplete: {int(st[1])} cells >= {self.nbins} and {int(st[2])} row "
@@ -463,28 +584,37 @@ class DeviceStats:
 
     # -- multi-GPU: rows shard, histograms add ----------------------------------------------------
     def allreduce(self, group=None, same_extents=False, rows_bound=None, compact=None, info=None,
-                  force_message=False):
+                  force_message=False, compact_bound=None):
         """Sums the partial statistics of all ranks (RCCL over xGMI on GPUs): one integer SUM
         all-reduce, see parallel.allreduce_stats_tensors.  `same_extents=True` when every rank
         passed the same max_count / max_total (no extent agreement round, no host sync);
         `rows_bound` (the same on every rank): an upper bound on the rows of the whole job - below
         2^32 the message travels in 32-bit words, half the bytes; `compact` (default: from 4096
-        columns on): only the occupied bins of every column travel; `info`: a dict that receives
-        the message size.  After it every rank holds the global statistics and solves redundantly;
-        there is no per-iteration communication."""
+        columns on, and always with an overflow store): only the occupied bins of every column
+        travel; `compact_bound` (with same_extents; the same on every rank): a promised upper bound
+        on the compact length - the message is sized from it and no host read happens (a longer
+        compact form raises status[7], reported by check()); `info`: a dict that receives the message
+        size and, in compact form, `compact_words`, the measured length (a caller's next bound).
+        After it every rank holds the global statistics and solves redundantly; there is no
+        per-iteration communication."""
         from .parallel import allreduce_stats_tensors
         if rows_bound is not None and 0 <= int(rows_bound) < (1 << 32):
             self._rows_bound = int(rows_bound)  # checked against the rows counted, in check()
-        (self.hist, self.histV, self.status, self.init_acc, self.nbins,
-         self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
-                                               self.K, self.nbins, self.tbins, group, same_extents,
-                                               rows_bound, compact, info, force_message)
+        with _phase("allreduce"):
+            (self.hist, self.histV, self.status, self.init_acc, self.nbins,
+             self.tbins) = allreduce_stats_tensors(self.hist, self.histV, self.status, self.init_acc,
+                                                   self.K, self.nbins, self.tbins, group, same_extents,
+                                                   rows_bound, compact, info, force_message,
+                                                   overflow=self, compact_bound=compact_bound)
         return self
 
     def merge_(self, other):
-        """In-place sum with another DeviceStats on the same device (logical shards)."""
+        """In-place sum with another DeviceStats on the same device (logical shards).  Host-side
+        torch arithmetic (off the hot path); the overflow records are appended by dme_overflow_append."""
         if other.K != self.K:
             raise ValueError("K differs")
+        if other.nbins > self.dense_bins:
+            self.dense_bins = other.nbins  # keep the other's dense cells dense
         self.reserve(other.nbins - 1, other.tbins - 1)
         self.hist.view(self.K, self.nbins)[:, :other.nbins] += other.hist.view(other.K, other.nbins)
         self.histV[:other.tbins] += other.histV
@@ -492,22 +622,43 @@ class DeviceStats:
         mx = torch.maximum(self.status[4:6], other.status[4:6])
         self.status += other.status
         self.status[4:6] = mx
+        if other.overflow is not None:
+            self.overflow_capacity = max(self.overflow_capacity, other.overflow_capacity)
+            self._need_overflow()
+            with _on(self.device):
+                _lib.check(_lib.lib().dme_overflow_append(_ptr(self.overflow), _ptr(other.overflow),
+                                                          _ptr(self.status), _stream()))
         return self
+
+    def _overflow_records(self):
+        """(columns, values, rows) of the overflow store as int64 host arrays."""
+        if self.overflow is None:
+            z = np.zeros(0, dtype=np.int64)
+            return z, z, z
+        head = self.overflow[:2].cpu().numpy()
+        used = int(min(head[0], head[1]))
+        rec = self.overflow[2:2 + 2 * used].cpu().numpy().reshape(used, 2)
+        kv = rec[:, 0].astype(np.uint64)
+        cols = (kv & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        keep = (cols < self.K) & (rec[:, 1] != 0)
+        return cols[keep], (kv >> np.uint64(32)).astype(np.int64)[keep], rec[keep, 1].copy()
 
     # -- persistence: statistics of row sets computed at different times or places add up -----------
     def save(self, path):
-        """Writes the statistics as a .npz file (the histograms' non-zero cells, the row-total
-        histogram, the mean accumulator, the status words).  The reference keeps U/V in memory
-        only; files written here can be loaded and merged (`load`, `merge_`) in any order, which
-        gives incremental estimation over data that arrives in pieces."""
+        """Writes the statistics as a .npz file (the histograms' non-zero cells - the dense ones and
+        the overflow records alike -, the row-total histogram, the mean accumulator, the status words).
+        The reference keeps U/V in memory only; files written here can be loaded and merged (`load`,
+        `merge_`) in any order, which gives incremental estimation over data that arrives in pieces.
+        Host-side torch / numpy work, off the hot path."""
         self.check()
         h = self.hist.view(self.K, self.nbins)
         nz = torch.nonzero(h)
+        ok, ov, on = self._overflow_records()
         np.savez(path, format=np.array([1]), K=np.array([self.K]),
                  nbins=np.array([self.nbins]), tbins=np.array([self.tbins]),
-                 cols=nz[:, 0].to(torch.int32).cpu().numpy(),
-                 bins=nz[:, 1].to(torch.int32).cpu().numpy(),
-                 counts=h[nz[:, 0], nz[:, 1]].cpu().numpy(),
+                 cols=np.concatenate([nz[:, 0].to(torch.int32).cpu().numpy(), ok.astype(np.int32)]),
+                 bins=np.concatenate([nz[:, 1].to(torch.int32).cpu().numpy(), ov.astype(np.int32)]),
+                 counts=np.concatenate([h[nz[:, 0], nz[:, 1]].cpu().numpy(), on]),
                  histV=self.histV.cpu().numpy(), init_acc=self.init_acc.cpu().numpy(),
                  status=self.status.cpu().numpy())
 
@@ -517,34 +668,79 @@ class DeviceStats:
             if int(f["format"][0]) != 1:
                 raise ValueError("unknown statistics file format")
             K, nbins, tbins = int(f["K"][0]), int(f["nbins"][0]), int(f["tbins"][0])
-            st = cls(K, nbins - 1, tbins - 1, device=device)
-            st.reserve(nbins - 1, tbins - 1)
-            dev = st.device
-            cols = torch.from_numpy(f["cols"].astype(np.int64)).to(dev)
-            bins = torch.from_numpy(f["bins"].astype(np.int64)).to(dev)
-            if cols.numel() and (int(cols.max()) >= K or int(bins.max()) >= st.nbins
-                                 or int(cols.min()) < 0 or int(bins.min()) < 0):
+            cols_h, bins_h = f["cols"].astype(np.int64), f["bins"].astype(np.int64)
+            counts_h = f["counts"].astype(np.int64)
+            if cols_h.size and (cols_h.max() >= K or cols_h.min() < 0 or bins_h.min() < 0):
                 raise ValueError("statistics file: cell index out of range")
-            st.hist.view(K, st.nbins)[cols, bins] = torch.from_numpy(f["counts"].astype(np.int64)).to(dev)
+            big = bins_h >= nbins  # cells that were overflow records
+            st = cls(K, nbins - 1, tbins - 1, device=device, dense_bins=max(nbins, 2),
+                     overflow_capacity=max(int(big.sum()) * 2, OVERFLOW_CAPACITY))
+            dev = st.device
+            cols = torch.from_numpy(cols_h[~big]).to(dev)
+            bins = torch.from_numpy(bins_h[~big]).to(dev)
+            st.hist.view(K, st.nbins)[cols, bins] = torch.from_numpy(counts_h[~big]).to(dev)
             st.histV[:tbins] = torch.from_numpy(f["histV"].astype(np.int64)).to(dev)
             st.init_acc.copy_(torch.from_numpy(f["init_acc"].astype(np.float64)).to(dev))
             st.status.copy_(torch.from_numpy(f["status"].astype(np.int64)).to(dev))
+            if big.any():
+                st._need_overflow()
+                n = int(big.sum())
+                rec = np.empty((n, 2), dtype=np.int64)
+                rec[:, 0] = cols_h[big] | (bins_h[big] << 32)
+                rec[:, 1] = counts_h[big]
+                st.overflow[2:2 + 2 * n] = torch.from_numpy(rec.reshape(-1)).to(dev)
+                st.overflow[0] = n
         return st
 
     # -- scan -------------------------------------------------------------------------------------
-    def finalize(self):
-        """Reverse suffix scan -> DeviceUV (the reference's U/V, exact integers + fp64 copies)."""
+    def finalize(self, ragged=None):
+        """Reverse suffix scan -> DeviceUV (the reference's U/V, exact integers + fp64 copies).
+        ragged: lay U out with every column at its own length (None: when an overflow store is in
+        use or the dense form would take RAGGED_MIN_CELLS cells or more; one host read of the two
+        lengths).  Dense-padded otherwise: no host read, which is what keeps estimate_async() on
+        BASELINE's K = 1000 shape free of synchronisation."""
         K, dev = self.K, self.device
-        ldU = max(self.nbins - 1, 1)
+        if ragged is None:
+            ragged = self.overflow is not None or K * self.nbins >= RAGGED_MIN_CELLS
+        if not ragged and self.overflow is not None:
+            raise ValueError("statistics with an overflow store have no dense-padded form")
+        L = _lib.lib()
         capV = max(self.tbins - 1, 1)
-        with _on(dev):
+        if ragged:
+            with _on(dev), _phase("scan"):
+                ext = torch.empty(K, dtype=torch.int64, device=dev)
+                plan = torch.empty(2 * (K + 1), dtype=torch.int64, device=dev)
+                off, slotoff = plan[:K + 1], plan[K + 1:]
+                _lib.check(L.dme_shard_extents(_ptr(self.hist), K, self.nbins, _ptr(ext), _stream()))
+                if self.overflow is not None:
+                    _lib.check(L.dme_overflow_extents(_ptr(self.overflow), K, _ptr(ext), _stream()))
+                _lib.check(L.dme_ragged_plan(_ptr(ext), K, _ptr(off), _ptr(slotoff), _stream()))
+                total, nslots = (int(v) for v in plan[[K, 2 * K + 1]].cpu())  # the one host read
+                tl = max(total, 1)
+                # U (int64) | V | lenU | lenV ; the compact cells are written where U goes and scanned
+                # in place (a thread writes U[off + v - 1] from the cells it read at that very index)
+                ibuf = torch.empty(tl + capV + K + 1, dtype=torch.int64, device=dev)
+                U, V = ibuf[:tl], ibuf[tl:tl + capV]
+                lenU, lenV = ibuf[tl + capV:tl + capV + K], ibuf[tl + capV + K:]
+                fbuf = torch.empty(tl + capV, dtype=torch.float64, device=dev)
+                Uf, Vf = fbuf[:tl], fbuf[tl:]
+                slotcol = torch.empty(max(nslots, 1), dtype=torch.int32, device=dev)
+                _lib.check(L.dme_shard_compact(_ptr(self.hist), K, self.nbins, _ptr(self.overflow),
+                                               _ptr(off), _ptr(U), total, _ptr(self.status), _stream()))
+                _lib.check(L.dme_suffix_scan_ragged(
+                    _ptr(U), _ptr(off), K, _ptr(self.histV), self.tbins, _ptr(U), _ptr(Uf), _ptr(lenU),
+                    _ptr(V), _ptr(Vf), _ptr(lenV), _ptr(slotoff), _ptr(slotcol), _stream()))
+            return DeviceUV(K, Uf, 1, lenU, Vf, lenV, U=U, V=V,
+                            ragged=(off, slotoff, slotcol, nslots, total))
+        ldU = max(self.nbins - 1, 1)
+        with _on(dev), _phase("scan"):
             # the scan writes every entry (padding included): no zero fill needed
             ibuf = torch.empty(K * ldU + capV + K + 1, dtype=torch.int64, device=dev)
             U, V = ibuf[:K * ldU], ibuf[K * ldU:K * ldU + capV]
             lenU, lenV = ibuf[K * ldU + capV:K * ldU + capV + K], ibuf[K * ldU + capV + K:]
             fbuf = torch.empty(K * ldU + capV, dtype=torch.float64, device=dev)
             Uf, Vf = fbuf[:K * ldU], fbuf[K * ldU:]
-            _lib.check(_lib.lib().dme_suffix_scan(
+            _lib.check(L.dme_suffix_scan(
                 _ptr(self.hist), K, self.nbins, _ptr(self.histV), self.tbins, _ptr(U), _ptr(Uf),
                 ldU, _ptr(lenU), _ptr(V), _ptr(Vf), _ptr(lenV), _stream()))
         return DeviceUV(K, Uf, ldU, lenU, Vf, lenV, U=U, V=V)
@@ -589,11 +785,15 @@ class PendingEstimate:
         uv, st = self.uv, self.stats
         ws, wsb = uv.workspace()
         n = ctypes.c_int64(0)
-        _lib.check(_lib.lib().dme_solve_enqueue(
-            _ptr(uv.Uf), uv.ldU, _ptr(uv.lenU), _ptr(uv.Vf), uv.capV, _ptr(uv.lenV), uv.K,
-            _ptr(self.alpha), self.iterations, self.hyperprior, _ptr(st.init_acc), _ptr(st.status),
-            self.buf.data_ptr() + 16 * 8, 0, self.cap, self.buf.data_ptr(), self.host.data_ptr(),
-            ws, wsb, self.launched, 0, ctypes.addressof(n), self.stream.cuda_stream))
+        tail = (_ptr(uv.lenU), _ptr(uv.Vf), uv.capV, _ptr(uv.lenV), uv.K,
+                _ptr(self.alpha), self.iterations, self.hyperprior, _ptr(st.init_acc), _ptr(st.status),
+                self.buf.data_ptr() + 16 * 8, 0, self.cap, self.buf.data_ptr(), self.host.data_ptr(),
+                ws, wsb, self.launched, 0, ctypes.addressof(n), self.stream.cuda_stream)
+        with _phase("solve"):
+            if uv.ragged is not None:
+                _lib.check(_lib.lib().dme_solve_enqueue_ragged(_ptr(uv.Uf), uv._rgp(), *tail))
+            else:
+                _lib.check(_lib.lib().dme_solve_enqueue(_ptr(uv.Uf), uv.ldU, *tail))
         self.launched += n.value
 
     def result(self):
@@ -606,8 +806,10 @@ class PendingEstimate:
                     break
                 self._enqueue()  # the default batch fell short: more launches, another wait
             res = self.host.tolist()
-            _lib.check(_lib.lib().dme_solve_finish(self.host.data_ptr(), self.uv.K, self.uv.ldU))
+            # data errors first: statistics that are incomplete (negative cells, counts beyond the
+            # bounds, a malformed rowptr) often make the solver fail too, and they are the cause
             info = self.stats._verdict(res[8:16])
+            _lib.check(_lib.lib().dme_solve_finish(self.host.data_ptr(), self.uv.K, self.uv.shape_key))
             out = SolveResult(self.alpha, res[:8], self.buf[16:].view(self.cap, 4), None, self.cap,
                               self.uv.K)
             out["info"] = info
@@ -683,6 +885,8 @@ class WeightedStats:
         integers)."""
         if not 0 <= c < self.C:
             raise IndexError("weight column out of range")
+        if uv.ragged is not None:
+            raise ValueError("weighted statistics add into a dense-padded DeviceUV (finalize(ragged=False))")
         if uv.ldU < self.nbins - 1 or uv.capV < self.tbins - 1:
             raise ValueError("DeviceUV too small for the weighted statistics")
         with _on(self.device):

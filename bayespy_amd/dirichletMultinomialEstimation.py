@@ -144,7 +144,9 @@ class CompressedRowData:
             tmp.add_dense(torch.from_numpy(Xe).to(st.device), max_count=int(Xe.max()),
                           max_total=int(Xe.sum(axis=1, dtype=np.int64).max()))
             tmp.check()
-            cut = _dev.DeviceStats(self.K, tmp.nbins - 1, tmp.tbins - 1, device=st.device)
+            cut = _dev.DeviceStats(self.K, tmp.nbins - 1, tmp.tbins - 1, device=st.device,
+                                   dense_bins=tmp.nbins, overflow_capacity=tmp.overflow_capacity)
+            cut.overflow = tmp.overflow  # (records of the hidden column K are skipped downstream)
             cut.hist = tmp.hist.view(self.K + 1, tmp.nbins)[:self.K].contiguous().view(-1)
             cut.histV = tmp.histV
             cut.init_acc = tmp.init_acc[:self.K].contiguous()
@@ -163,7 +165,8 @@ class CompressedRowData:
             if self._wstats is not None:
                 self._wstats.check()
                 st.reserve(self._wstats.nbins - 1, self._wstats.tbins - 1)
-            self._uv = st.finalize()
+            # weighted suffix sums add into a dense-padded U
+            self._uv = st.finalize(ragged=False if self._wstats is not None else None)
             if self._wstats is not None:
                 self._wstats.add_into(self._uv)
         return self._uv

@@ -43,7 +43,7 @@ COMPACT_MIN_WORDS = 1 << 20  # or from this many bins on when the ranks agree on
 
 def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, group=None,
                             same_extents=False, rows_bound=None, compact=None, info=None,
-                            force_message=False):
+                            force_message=False, overflow=None, compact_bound=None):
     """All-reduces one rank's partial statistics.  Tensors may live on any device the process
     group supports.  Returns (hist, histV, status, init_acc, nbins, tbins) holding the global
     statistics on every rank.
@@ -74,7 +74,17 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     read of the compact length).  With many columns nearly all of them stop far below the largest
     count of any: BASELINE configs[3] (K = 50 000) sends a few MB instead of K x nbins words.
 
-    `info` (a dict, optional) receives message_bytes and, in compact form, extents_bytes.
+    `overflow`: the DeviceStats that owns the histograms (its `.overflow` store holds the counts
+    beyond the dense bins, include/dme_hip.h).  A store on any rank makes the message compact: the
+    records are added into the compact form before the sum and the merged cells beyond the dense
+    bins are written back as records afterwards.
+    `compact_bound` (GPU tensors, with same_extents; the same on every rank): a promised upper bound
+    on the compact length.  The message is sized from it and the lengths stay on the device - no host
+    read in the whole call; a compact form that outgrows the bound raises status[7], which travels
+    in the message and is reported by DeviceStats.check() on every rank.
+
+    `info` (a dict, optional) receives message_bytes and, in compact form, extents_bytes and (measured
+    path) compact_words.
     `force_message`: build, reduce and read the message even in a group of one rank (rehearsals of
     the RCCL code path on a single GPU)."""
     import torch.distributed as dist
@@ -83,35 +93,52 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
     if dist.get_world_size(group) == 1 and not force_message:
         return hist, histV, status, init_acc, nbins, tbins
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    store = overflow.overflow if overflow is not None else None
     if compact is None:
         # (a rule every rank evaluates alike: K always is the same, nbins only when agreed beforehand)
         compact = K >= COMPACT_MIN_K or (same_extents and K * nbins >= COMPACT_MIN_WORDS)
+    if same_extents and store is not None:
+        compact = True  # (the same bounds on every rank: every rank has a store)
     nb, tb = nbins, tbins
+    if not compact and not same_extents:
+        # the histogram extents - and whether any rank keeps an overflow store, which makes the
+        # message compact on every rank - agreed in one MAX
+        ext = torch.tensor([nbins, tbins, 0 if store is None else 1], dtype=torch.int64,
+                           device=hist.device)
+        dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
+        nb, tb, any_store = (int(v) for v in ext.cpu())
+        if any_store:
+            compact = True
+        else:
+            hist = grow_hist(hist, K, nbins, nb)
+            histV = grow_vec(histV, tb)
     off = None
     if compact:
         # the columns' extents, and with them the two histogram extents, agreed in one MAX
-        ext = torch.empty(K + 2, dtype=torch.int64, device=hist.device)
-        ext[K], ext[K + 1] = nbins, tbins
-        _column_extents(hist, K, nbins, ext)
+        ext = torch.empty(K + 3, dtype=torch.int64, device=hist.device)
+        ext[K], ext[K + 1], ext[K + 2] = nbins, tbins, 0 if store is None else 1
+        _column_extents(hist, K, nbins, ext, store)
         _sync_for_gloo(ext, group)
         dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
         off = torch.empty(K + 1, dtype=torch.int64, device=hist.device)
         _column_offsets(ext, K, off)
-        nb, tb, total = (int(v) for v in torch.stack([ext[K], ext[K + 1], off[K]]).cpu())
+        if compact_bound is not None and same_extents and hist.is_cuda:
+            total = int(compact_bound)  # promised: nothing is read back
+        else:
+            nb, tb, any_store, total = (int(v) for v in
+                                        torch.stack([ext[K], ext[K + 1], ext[K + 2], off[K]]).cpu())
+            if any_store and store is None and overflow is not None:
+                overflow._need_overflow()  # another rank's records will come back to this one
+                store = overflow.overflow
+            if info is not None:
+                info["compact_words"] = total
         histV = grow_vec(histV, tb)
-        full, full_bins = hist, nbins
-        hist = _to_compact(full, K, full_bins, off, total)
+        hist = _to_compact(hist, K, nbins, off, total, store, status)
         if info is not None:
-            info["extents_bytes"] = (K + 2) * 8
-    elif not same_extents:
-        ext = torch.tensor([nbins, tbins], dtype=torch.int64, device=hist.device)
-        dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
-        nb, tb = (int(v) for v in ext.cpu())
-        hist = grow_hist(hist, K, nbins, nb)
-        histV = grow_vec(histV, tb)
+            info["extents_bytes"] = (K + 3) * 8
     out = _sum_message(hist, histV, status, init_acc, K, group, world, rank, rows_bound, info)
     if compact:
-        out = (_from_compact(out[0], K, nb, off),) + out[1:]
+        out = (_from_compact(out[0], K, nb, off, store, out[2]),) + out[1:]
     return out + (nb, tb)
 
 
@@ -124,13 +151,16 @@ def _sync_for_gloo(t, group):
         torch.cuda.current_stream(t.device).synchronize()
 
 
-def _column_extents(hist, K, nbins, ext):
-    """ext[k] = the largest occupied bin of column k (dme_shard_extents; torch for host tensors)."""
+def _column_extents(hist, K, nbins, ext, store=None):
+    """ext[k] = the largest occupied bin of column k, overflow records included (dme_shard_extents,
+    dme_overflow_extents; torch for host tensors)."""
     if hist.is_cuda:
         from . import _lib
         from .device import _on, _ptr, _stream
         with _on(hist.device):
             _lib.check(_lib.lib().dme_shard_extents(_ptr(hist), K, nbins, _ptr(ext), _stream()))
+            if store is not None:
+                _lib.check(_lib.lib().dme_overflow_extents(_ptr(store), K, _ptr(ext), _stream()))
     else:
         bins = torch.arange(nbins, dtype=torch.int64)
         ext[:K] = ((hist.view(K, nbins) != 0) * bins).max(dim=1).values
@@ -147,16 +177,19 @@ def _column_offsets(ext, K, off):
         off[1:] = torch.cumsum(ext[:K], 0)
 
 
-def _to_compact(hist, K, nbins, off, total):
+def _to_compact(hist, K, nbins, off, total, store=None, status=None):
+    """`total` words of compact form: the measured length, or a promised bound (GPU tensors; the words
+    behind the true length are zeroed, a longer form raises status[7])."""
     out = torch.empty(max(total, 1), dtype=torch.int64, device=hist.device)[:total]
-    if total == 0:
-        return out
     if hist.is_cuda:
         from . import _lib
         from .device import _on, _ptr, _stream
-        with _on(hist.device):
-            _lib.check(_lib.lib().dme_shard_compact(_ptr(hist), K, nbins, _ptr(off), _ptr(out),
-                                                    _stream()))
+        if total:
+            with _on(hist.device):
+                _lib.check(_lib.lib().dme_shard_compact(_ptr(hist), K, nbins, _ptr(store), _ptr(off),
+                                                        _ptr(out), total, _ptr(status), _stream()))
+        return out
+    if total == 0:
         return out
     n = (off[1:] - off[:-1])
     wide = max(nbins, int(n.max()) + 1)
@@ -165,16 +198,21 @@ def _to_compact(hist, K, nbins, off, total):
     return h[(bins[None, :] >= 1) & (bins[None, :] <= n[:, None])].contiguous()
 
 
-def _from_compact(comp, K, nbins, off):
+def _from_compact(comp, K, nbins, off, store=None, status=None):
     hist = torch.empty(K * nbins, dtype=torch.int64, device=comp.device)
     if comp.is_cuda:
         from . import _lib
         from .device import _on, _ptr, _stream
         if comp.numel() == 0:
             return hist.zero_()
+        L = _lib.lib()
         with _on(comp.device):
-            _lib.check(_lib.lib().dme_shard_expand(_ptr(comp), K, nbins, _ptr(off), _ptr(hist),
-                                                   _stream()))
+            if store is not None:
+                # the records went into the compact form; the merged cells beyond the dense bins come
+                # back as fresh records
+                _lib.check(L.dme_overflow_init(_ptr(store), (store.numel() - 2) // 2, _stream()))
+            _lib.check(L.dme_shard_expand(_ptr(comp), comp.numel(), K, nbins, _ptr(off), _ptr(hist),
+                                          _ptr(store), _ptr(status), _stream()))
         return hist
     hist.zero_()
     n = (off[1:] - off[:-1])

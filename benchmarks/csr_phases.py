@@ -38,7 +38,7 @@ def main():
         status = torch.zeros(8, dtype=torch.int64, device="cuda")
         _lib.check(L.dme_stats_csr_i32(rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), N, nnz, K,
                                        hist.data_ptr(), nbins, histV.data_ptr(), tbins, acc.data_ptr(),
-                                       status.data_ptr(), ws.data_ptr() + off, need,
+                                       status.data_ptr(), 0, ws.data_ptr() + off, need,
                                        torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
     ts = ws[off:off + 64].view(torch.int64).cpu().tolist()

@@ -69,7 +69,7 @@ def main():
             if step >= 2:
                 ms.append(e0.elapsed_time(e1))
         assert info["rows"] == N
-        uv = st.finalize()
+        uv = st.finalize(ragged=False)
         U = uv.Ui.view(K, uv.ldU)
         colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
         big = 0

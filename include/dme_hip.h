@@ -9,9 +9,18 @@
  *
  * Conventions
  *   - every pointer marked [dev] is a device pointer (hipMalloc / torch tensor data_ptr()),
- *     owned by the caller; the library allocates no device memory and keeps no state between
- *     calls (dme_solve only: 64 bytes of pinned host memory per host thread for its completion
- *     poll, allocated on first use);
+ *     owned by the caller; the library allocates no device memory and keeps nothing of a call's
+ *     DATA.  What it does keep between calls, all of it small and none of it visible in results:
+ *       per host thread  - the text of dme_last_error(); the launch structure pinned with
+ *                          dme_solve_set_path(); the CU limit of dme_set_cu_limit(); 64 bytes of
+ *                          pinned host memory for dme_solve's completion poll (allocated on first
+ *                          use, never freed); the launch-count hint of the solver: how many
+ *                          launches this thread's previous solve of the same (K, ldU) needed, which
+ *                          sizes the first batch of the next one (it changes how many launches are
+ *                          enqueued, never what they compute);
+ *       per process      - per device: the address of dme_eval_noalloc's static scratch array and
+ *                          "attribute set" flags of kernels that need more than 64 KB of LDS;
+ *                          the device's CU count;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - return value: DME_OK or a DME_ERR_* code; the text is in dme_last_error() (thread-local);
  *   - all launches are asynchronous on `stream` unless the entry says it synchronises;
@@ -26,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DME_ABI_VERSION 1
+#define DME_ABI_VERSION 2  /* 2: overflow store, ragged U/V, bounded compact message */
 
 #define DME_OK 0
 #define DME_ERR_INVALID_ARG 1   /* bad shape / pointer / alignment                               */
@@ -43,17 +52,21 @@ const char* dme_last_error(void);
 
 /* Number of compute units of the current device (used by callers to size workspaces). */
 int dme_device_cus(void);
-/* For callers that run the library on a CU-MASKED stream (hipExtStreamCreateWithCUMask): every launch
- * of the calling thread is sized for `cus` compute units from now on (grids of one workgroup per CU,
- * the solver's share of workgroups); 0 restores the device's own count.  No counterpart in the
- * reference.  Used by benchmarks/overlap_probe.py, which runs the solver of one estimation on a few
- * CUs beside the statistics pass of the next. */
+
+/* ---- EXPERIMENTAL: not part of the drop-in path, may change or go ----------------------------
+ * Kept for benchmarks/overlap_probe.py only, which ran the solver of one estimation on a few CUs
+ * beside the statistics pass of the next; the measurement did not pay (+7 % at
+ * one GPU's share of an 8-GPU job, -1.6 % on the bench) and nothing in bayespy_amd/ or bench.py
+ * calls these.  No counterpart in the reference.
+ *   dme_set_cu_limit: every launch of the calling thread is sized for `cus` compute units from now
+ *   on (grids of one workgroup per CU, the solver's share of workgroups); 0 restores the device's own
+ *   count.  dme_stream_create_masked: a stream whose kernels run only on the compute units whose
+ *   bits are set in `mask` (nwords 32-bit words; bit i = CU i in the HIP runtime's numbering:
+ *   hipExtStreamCreateWithCUMask); dme_stream_destroy ends it. */
 int dme_set_cu_limit(int cus);
-/* A stream whose kernels run only on the compute units whose bits are set in `mask` (nwords 32-bit
- * words; bit i = CU i in the HIP runtime's numbering: hipExtStreamCreateWithCUMask), and its end.  For
- * the same callers as dme_set_cu_limit. */
 int dme_stream_create_masked(const uint32_t* mask /*[host]*/, int nwords, void** stream /*out*/);
 int dme_stream_destroy(void* stream);
+/* ---- end of the experimental entries --------------------------------------------------------- */
 
 /* ---------------------------------------------------------------------------------------------
  * Extents for the histograms.  The reference lengthens U[k] / V as rows arrive (DE/dme.py:118, :122);
@@ -72,6 +85,28 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
                        int64_t N, int64_t nnz, uint64_t* out /*[dev][2]*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Overflow store: where a statistics pass puts the cells whose count does not fit the dense
+ * histogram (x_ik = v >= nbins).  The reference's U[k] are lists of their own lengths
+ * (DE/dme.py:118), so one outlier count costs it one long list; a dense K x nbins histogram would
+ * pay K times that.  With a store, hist keeps a width the caller chooses and every larger count is
+ * a 16-byte record:
+ *     uint64 head[2] = {used, capacity};  struct {uint32 column, value; uint64 rows;} record[capacity]
+ * `used` counts every attempt; records beyond `capacity` are dropped and reported in status[1].
+ * A pass appends records with rows = 1 (equal cells repeat); dme_shard_compact adds them into the
+ * compact form, dme_shard_expand writes merged ones back.  No counterpart in the reference.
+ *   dme_overflow_bytes(capacity)   = 16 + 16 * capacity
+ *   dme_overflow_init              head = {0, capacity}
+ *   dme_overflow_extents           ext[k] = max(ext[k], value) over the records (after dme_shard_extents)
+ *   dme_overflow_append            dst += the records of src (status[1] += rows of those dst cannot hold)
+ * ------------------------------------------------------------------------------------------- */
+int64_t dme_overflow_bytes(int64_t capacity);
+int dme_overflow_init(uint64_t* store /*[dev], 16-byte aligned*/, int64_t capacity, void* stream);
+int dme_overflow_extents(const uint64_t* overflow /*[dev]*/, int64_t K, int64_t* ext /*[dev][K]*/,
+                         void* stream);
+int dme_overflow_append(uint64_t* dst /*[dev]*/, const uint64_t* src /*[dev]*/,
+                        uint64_t* status /*[dev][8] or NULL*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Statistics build.  Replaces CompressedRowData.appendRow (DE/dme.py:113-123) applied to every
  * row, plus the CLI's mean accumulator (DE/fdp.py:87-89), in one pass over the count matrix.
  *
@@ -82,13 +117,16 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  * dme_suffix_scan turns hist/histV into the reference's U/V.  Integer results are exact.
  *
  * status[8] [dev] (uint64, += ; caller zeroes):
- *     [0] rows processed        [1] cells with count >= nbins (NOT counted: result incomplete)
+ *     [0] rows processed        [1] cells with count >= nbins that no overflow store took (NOT
+ *                                   counted: result incomplete)
  *     [2] rows with total >= tbins (NOT counted)              [3] negative cells (i32 only)
  *     [4] max count seen        [5] max row total seen
  *     [6] CSR only: malformed rowptr - negative, decreasing, or spanning more entries than the nnz
  *         passed (the partitioned pass then counts nothing; the atomics pass skips such rows)
- * The caller must check status[1..3] == 0 and status[6] == 0 (they are data errors, reported after the fact so
- * that the pass stays asynchronous).
+ *     [7] internal faults (a bounded in-kernel wait that expired; a compact all-reduce message that
+ *         outgrew the capacity its caller promised): the result is incomplete
+ * The caller must check status[1..3] == 0 and status[6..7] == 0 (data errors and faults are reported after
+ * the fact so that the pass stays asynchronous).
  *
  * X is row-major, `ld` elements between rows (ld >= K).  Rows of 8 uint16 / 4 int32 columns or more
  * are read in 16-byte vectors whatever their pitch, alignment and K (global memory takes unaligned
@@ -99,6 +137,7 @@ int dme_bounds_csr_i32(const int64_t* rowptr /*[dev][N+1]*/, const int32_t* vals
  * 8 waves.  Narrow rows that lie back to back from a 16-byte-aligned address: uint16 K = 4 as two
  * rows per vector, K = 2 (both element types) as pair counts (see dme_stats.hip).  Beyond the column limits:
  * DME_ERR_UNSUPPORTED (use the CSR entry).
+ * overflow [dev] or NULL: an overflow store (above) for the cells with count >= nbins.
  * workspace [dev], 256-byte aligned: dme_stats_workspace_bytes(N, K) bytes.
  * ------------------------------------------------------------------------------------------- */
 int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);
@@ -106,12 +145,14 @@ int64_t dme_stats_workspace_bytes(int64_t N, int64_t K);
 int dme_stats_dense_u16(const uint16_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
                         uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,
                         int64_t tbins, double* init_acc /*[dev]*/, uint64_t* status /*[dev]*/,
-                        void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
+                        uint64_t* overflow /*[dev] or NULL*/, void* workspace /*[dev]*/,
+                        int64_t workspace_bytes, void* stream);
 
 int dme_stats_dense_i32(const int32_t* X /*[dev]*/, int64_t N, int64_t K, int64_t ld,
                         uint64_t* hist /*[dev]*/, int64_t nbins, uint64_t* histV /*[dev]*/,
                         int64_t tbins, double* init_acc /*[dev]*/, uint64_t* status /*[dev]*/,
-                        void* workspace /*[dev]*/, int64_t workspace_bytes, void* stream);
+                        uint64_t* overflow /*[dev] or NULL*/, void* workspace /*[dev]*/,
+                        int64_t workspace_bytes, void* stream);
 
 /* Dense rows wider than the entries above take: compress them to CSR on the device and use
  * dme_stats_csr_i32.  dme_dense_row_nnz_* writes counts[i] = the non-zero cells of row i;
@@ -140,8 +181,8 @@ int64_t dme_stats_csr_workspace_bytes(int64_t N, int64_t nnz, int64_t K);
 int dme_stats_csr_i32(const int64_t* rowptr /*[dev]*/, const int32_t* colidx /*[dev]*/,
                       const int32_t* vals /*[dev]*/, int64_t N, int64_t nnz, int64_t K,
                       uint64_t* hist, int64_t nbins, uint64_t* histV, int64_t tbins,
-                      double* init_acc, uint64_t* status, void* workspace,
-                      int64_t workspace_bytes, void* stream);
+                      double* init_acc, uint64_t* status, uint64_t* overflow /*[dev] or NULL*/,
+                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Reverse suffix scan: value histograms -> the reference's compressed statistics
@@ -157,6 +198,26 @@ int dme_suffix_scan(const uint64_t* hist /*[dev]*/, int64_t K, int64_t nbins,
                     double* Uf /*[dev] or NULL*/, int64_t ldU, int64_t* lenU /*[dev] [K]*/,
                     int64_t* V /*[dev]*/, double* Vf /*[dev] or NULL*/,
                     int64_t* lenV /*[dev] [1]*/, void* stream);
+
+/* RAGGED statistics: every column at its own length, as the reference's lists are (DE/dme.py:118,
+ * :122).  The count histograms in compact form (dme_shard_extents [+ dme_overflow_extents] ->
+ * dme_ragged_plan -> dme_shard_compact, below) are scanned in place of hist, and U / Uf take the same
+ * places: U[k][n] = U[off[k] + n], n in [0, off[k+1] - off[k]).  K = 50 000 columns with one count of
+ * 100 000 then cost their own ~1e5 + sum of the other columns' extents, not K x 100 001 cells.
+ *   dme_ragged_plan   off[k] = ext[0] + ... + ext[k-1] (as dme_shard_offsets) and slotoff[k] = the same
+ *                     over ceil(ext / DME_SEGMENT_TERMS): the solver's slots (dme_ragged_t below);
+ *                     both [K + 1].  The caller reads off[K] and slotoff[K] back to size the arrays.
+ *   dme_suffix_scan_ragged   compact [off[K]] -> U, Uf [off[K]], lenU[K]; histV -> V, Vf, lenV as
+ *                     dme_suffix_scan; slotcol[s] = the column of slot s (with slotoff; both or neither). */
+#define DME_SEGMENT_TERMS 256
+int dme_ragged_plan(const int64_t* ext /*[dev][K]*/, int64_t K, int64_t* off /*[dev][K+1] out*/,
+                    int64_t* slotoff /*[dev][K+1] out*/, void* stream);
+int dme_suffix_scan_ragged(const uint64_t* compact /*[dev][off[K]]*/, const int64_t* off /*[dev][K+1]*/,
+                           int64_t K, const uint64_t* histV /*[dev]*/, int64_t tbins,
+                           int64_t* U /*[dev][off[K]]*/, double* Uf /*[dev][off[K]] or NULL*/,
+                           int64_t* lenU /*[dev][K]*/, int64_t* V /*[dev]*/, double* Vf /*[dev] or NULL*/,
+                           int64_t* lenV /*[dev][1]*/, const int64_t* slotoff /*[dev][K+1] or NULL*/,
+                           int32_t* slotcol /*[dev][slotoff[K]] or NULL*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weighted rows: appendRow(row, weight) with weight != 1 (DE/dme.py:119, :123 add `weight`; used
@@ -235,26 +296,36 @@ int dme_shard_unpack32(const uint32_t* msg /*[dev]*/, int64_t nh, int64_t nv, in
                        uint64_t* histV64 /*[dev][nv] out*/, uint64_t* status /*[dev][8] out*/,
                        double* init_acc /*[dev][K] out*/, void* stream);
 
-/* Compact form of hist for many columns (BASELINE configs[3], K = 50 000: nbins is set by the
- * largest count of any column, nearly every column stops far below it).  What travels are the bins
- * 1 .. ext[k] of every column laid end to end, `compact`, passed to dme_shard_pack / _pack32 in
- * place of hist with nh = off[K]:
- *   dme_shard_extents  ext[k] = the largest occupied bin of column k (0: none)   - then a MAX
- *                      all-reduce of ext over the ranks (the caller's);
+/* Compact form of hist (BASELINE configs[3], K = 50 000: nbins is set by the largest count of any
+ * column, nearly every column stops far below it; also the form the ragged scan reads).  What travels
+ * are the bins 1 .. ext[k] of every column laid end to end, `compact`, passed to dme_shard_pack /
+ * _pack32 in place of hist with nh = the compact capacity:
+ *   dme_shard_extents  ext[k] = the largest occupied bin of column k (0: none); dme_overflow_extents
+ *                      raises it by the overflow records - then a MAX all-reduce of ext over the ranks
+ *                      (the caller's);
  *   dme_shard_offsets  off[k] = ext[0] + ... + ext[k-1], off[K] = the compact length;
- *   dme_shard_compact  compact[off[k] + v - 1] = hist[k*nbins + v],  v in 1 .. ext[k];
- *   dme_shard_expand   the way back after the sum: fills hist (every bin; zeros outside 1 .. ext[k]).
+ *   dme_shard_compact  compact[off[k] + v - 1] = hist[k*nbins + v] (+ the rows of the overflow records
+ *                      of (k, v)), v in 1 .. ext[k]; the words from off[K] to `capacity` are zeroed.  A
+ *                      caller that sizes `compact` from a promised bound instead of reading off[K] back
+ *                      passes that bound as `capacity`: nothing is written beyond it and
+ *                      off[K] > capacity raises status[7] (checked after the fact, like the other
+ *                      status words);
+ *   dme_shard_expand   the way back after the sum: fills hist (every bin; zeros outside 1 .. ext[k]);
+ *                      cells beyond the dense bins go to `overflow` (NULL, or a store that is full:
+ *                      status[1] counts their rows).
  * No counterpart in the reference (one process). */
 int dme_shard_extents(const uint64_t* hist /*[dev][K*nbins]*/, int64_t K, int64_t nbins,
                       int64_t* ext /*[dev][K] out*/, void* stream);
 int dme_shard_offsets(const int64_t* ext /*[dev][K]*/, int64_t K, int64_t* off /*[dev][K+1] out*/,
                       void* stream);
 int dme_shard_compact(const uint64_t* hist /*[dev][K*nbins]*/, int64_t K, int64_t nbins,
-                      const int64_t* off /*[dev][K+1]*/, uint64_t* compact /*[dev][off[K]] out*/,
-                      void* stream);
-int dme_shard_expand(const uint64_t* compact /*[dev][off[K]]*/, int64_t K, int64_t nbins,
-                     const int64_t* off /*[dev][K+1]*/, uint64_t* hist /*[dev][K*nbins] out*/,
-                     void* stream);
+                      const uint64_t* overflow /*[dev] or NULL*/, const int64_t* off /*[dev][K+1]*/,
+                      uint64_t* compact /*[dev][capacity] out*/, int64_t capacity,
+                      uint64_t* status /*[dev][8] or NULL*/, void* stream);
+int dme_shard_expand(const uint64_t* compact /*[dev][capacity]*/, int64_t capacity, int64_t K,
+                     int64_t nbins, const int64_t* off /*[dev][K+1]*/,
+                     uint64_t* hist /*[dev][K*nbins] out*/, uint64_t* overflow /*[dev] or NULL*/,
+                     uint64_t* status /*[dev][8] or NULL*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Solver.  U is dense-padded fp64: U[k][n] = Uf[k*ldU + n] for n < lenU[k]; V = Vf[0..lenV).
@@ -283,8 +354,11 @@ int dme_eval(const double* Uf, int64_t ldU, const int64_t* lenU, const double* V
  * library, DME_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.  Shapes whose
  * dme_solver_workspace_bytes(K, ldU, capV) exceeds that are rejected with DME_ERR_WORKSPACE (use
  * dme_eval).  Calls no hipMalloc / hipFree / allocating routine; the first call on a device looks
- * up the array's address there (hipGetSymbolAddress).  All calls on one GPU share the array:
- * calls that overlap on one GPU (other streams or threads) race - serialise them.  Asynchronous. */
+ * up the array's address there (hipGetSymbolAddress, which may load the library's code object and is
+ * not a stream operation): make ONE eager call per device - any small shape will do - before calling
+ * under HIP graph capture; later calls read the cached address with one atomic load.  All calls on one
+ * GPU share the array: calls that overlap on one GPU (other streams or threads) race - serialise them.
+ * Asynchronous. */
 #define DME_NOALLOC_SCRATCH_BYTES (8LL << 20)
 int dme_eval_noalloc(const double* Uf, int64_t ldU, const int64_t* lenU, const double* Vf,
                      int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
@@ -350,6 +424,42 @@ int dme_solve_enqueue(const double* Uf, int64_t ldU, const int64_t* lenU, const 
                       void* workspace, int64_t workspace_bytes, int64_t first, int64_t count,
                       int64_t* enqueued /*[host][1] out*/, void* stream);
 int dme_solve_finish(const int64_t* result_host /*[host][16]*/, int64_t K, int64_t ldU);
+
+/* The solver on RAGGED statistics (dme_suffix_scan_ragged): the same kernels, device functions and
+ * order of operations as the dense-padded entries - a column's terms, its slots in the partial-sum
+ * table and the memory both take follow its own length.  `ragged` is a HOST struct of device pointers.
+ * beta == NULL and has_W == 0 select the scalar hyperprior (dme_eval / dme_solve), otherwise the
+ * (Beta, W) one (dme_eval_cpt / dme_solve_cpt; hyperprior must then be 0).  Workspace:
+ * dme_solver_workspace_bytes_ragged(K, ragged->nslots, capV).  dme_solve_finish takes ragged->nslots in
+ * place of ldU. */
+typedef struct dme_ragged {
+    const int64_t* offU;    /* [dev][K+1]  U[k][n] = Uf[offU[k] + n], n < offU[k+1] - offU[k]          */
+    const int64_t* slotoff; /* [dev][K+1]  column k owns the slots [slotoff[k], slotoff[k+1]) of
+                                           DME_SEGMENT_TERMS terms each                                 */
+    const int32_t* slotcol; /* [dev][nslots] the column of every slot                                   */
+    int64_t nslots;         /* slotoff[K]                                                               */
+    int64_t total;          /* offU[K]: the length of Uf                                                */
+} dme_ragged_t;
+int64_t dme_solver_workspace_bytes_ragged(int64_t K, int64_t nslots, int64_t capV);
+int dme_eval_ragged(const double* Uf, const dme_ragged_t* ragged /*[host]*/, const int64_t* lenU,
+                    const double* Vf, int64_t capV, const int64_t* lenV, int64_t K, const double* alpha,
+                    double hyperprior, const double* beta /*[dev][K] or NULL*/, double W, int has_W,
+                    double* out_scalars /*[dev][4]*/, double* out_grad, double* out_hdiag,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+int dme_solve_ragged(const double* Uf, const dme_ragged_t* ragged /*[host]*/, const int64_t* lenU,
+                     const double* Vf, int64_t capV, const int64_t* lenV, int64_t K, double* alpha,
+                     int64_t iterations, double hyperprior, const double* beta /*[dev][K] or NULL*/,
+                     double W, int has_W, double* trace, double* trace_alpha, int64_t trace_cap,
+                     int64_t* result, int64_t* result_host, double* final_loss, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int dme_solve_enqueue_ragged(const double* Uf, const dme_ragged_t* ragged /*[host]*/,
+                             const int64_t* lenU, const double* Vf, int64_t capV, const int64_t* lenV,
+                             int64_t K, double* alpha, int64_t iterations, double hyperprior,
+                             const double* init_acc, const uint64_t* status, double* trace,
+                             double* trace_alpha, int64_t trace_cap, int64_t* result /*[dev][16]*/,
+                             int64_t* result_host /*[host][16]*/, void* workspace,
+                             int64_t workspace_bytes, int64_t first, int64_t count,
+                             int64_t* enqueued /*[host][1] out*/, void* stream);
 
 /* Launch structure of dme_solve / dme_solve_cpt, for the calling host thread.  The three structures
  * run the same device functions in the same order and return the same bits; the choice is by size:

@@ -49,7 +49,7 @@ def test_ctypes_table_matches_header_arity():
 def test_abi_version_and_sizes_without_gpu():
     from bayespy_amd import _lib
     L = _lib.lib()
-    assert L.dme_abi_version() == 1
+    assert L.dme_abi_version() == _lib.ABI_VERSION == 2
     assert L.dme_solver_workspace_bytes(1000, 500, 500) > 0
     assert L.dme_solver_workspace_bytes(0, 1, 1) == -1
     assert L.dme_stats_workspace_bytes(10_000_000, 1000) > 256 * 1000 * 8
@@ -66,12 +66,12 @@ def test_argument_validation_needs_no_gpu():
     """Bad shapes are rejected before any HIP call."""
     from bayespy_amd import _lib
     L = _lib.lib()
-    rc = L.dme_stats_dense_u16(0, 10, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0)
+    rc = L.dme_stats_dense_u16(0, 10, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG
     assert b"bad shape" in L.dme_last_error()
-    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 0, 0, 2, 0, 2, 0, 0, 0, 0, 0)
+    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 0, 0, 2, 0, 2, 0, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG and b"bad shape" in L.dme_last_error()
-    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 7, 0, 2, 0, 2, 0, 0, 0, 0, 0)
+    rc = L.dme_stats_csr_i32(0, 0, 0, 5, 10, 7, 0, 2, 0, 2, 0, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG and b"null output" in L.dme_last_error()
     rc = L.dme_suffix_scan(0, 0, 1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0)
     assert rc == _lib.ERR_INVALID_ARG

@@ -223,17 +223,37 @@ def _nccl_one_rank(rank, port, out):
     X[5, 7] = 900
     Xd = torch.from_numpy(X).cuda()
     res = {}
-    for name, kw in (("words64", {}), ("words32", {"same_extents": True, "rows_bound": N}),
-                     ("compact", {"compact": True, "rows_bound": N})):
+    mt = int(X.sum(axis=1).max())
+    info = {}
+    for name, skw, kw in (
+            ("words64", {}, {}), ("words32", {}, {"same_extents": True, "rows_bound": N}),
+            ("compact", {}, {"compact": True, "rows_bound": N, "info": info}),
+            # counts of 64 and more (the 900 among them) as records of an overflow store: they travel
+            # inside the compact form and come back as records
+            ("overflow", {"dense_bins": 64}, {"same_extents": True, "rows_bound": N}),
+            # the compact message sized from a promised bound: no host read in the call
+            ("bounded", {}, {"compact": True, "same_extents": True, "rows_bound": N,
+                             "compact_bound": 40000}),
+            ("bounded_overflow", {"dense_bins": 64}, {"same_extents": True, "compact_bound": 40000})):
         pend = []
         for _ in range(3):  # enqueued back to back, as bench.py does: no host wait in between
-            st = device.DeviceStats(K, 900, int(X.sum(axis=1).max()))
-            st.add_dense(Xd, max_count=900, max_total=int(X.sum(axis=1).max()))
+            st = device.DeviceStats(K, 900, mt, **skw)
+            st.add_dense(Xd, max_count=900, max_total=mt)
             st.allreduce(force_message=True, **kw)
             pend.append(st.estimate_async(50))
         outs = [p.result() for p in pend]
         U, V = outs[-1]["uv"].to_lists()
         res[name] = (U, V, outs[-1]["info"]["rows"], outs[-1]["alpha"], [o["n_iters"] for o in outs])
+    res["compact_words"] = info["compact_words"]
+    # a compact bound that the statistics break: check() says so on every rank
+    small = device.DeviceStats(K, 900, mt)
+    small.add_dense(Xd, max_count=900, max_total=mt)
+    small.allreduce(force_message=True, compact=True, same_extents=True, compact_bound=100)
+    try:
+        small.check()
+        res["compact_bound_error"] = ""
+    except RuntimeError as ex:
+        res["compact_bound_error"] = str(ex)
     ref = device.DeviceStats(K, 900, int(X.sum(axis=1).max()))
     ref.add_dense(Xd, max_count=900, max_total=int(X.sum(axis=1).max()))
     o = ref.estimate_async(50).result()
@@ -266,8 +286,10 @@ def test_rccl_code_path_with_one_rank():
     out = mgr.dict()
     mp.spawn(_nccl_one_rank, args=(port, out), nprocs=1, join=True)
     plain = out["plain"]
-    for name in ("words64", "words32", "compact"):
+    for name in ("words64", "words32", "compact", "overflow", "bounded", "bounded_overflow"):
         U, V, rows, alpha, iters = out[name]
         assert U == plain[0] and V == plain[1] and rows == plain[2], name
         assert np.array_equal(alpha, plain[3]) and iters == plain[4], name
     assert "rows_bound" in out["bound_error"]
+    assert 100 < out["compact_words"] <= 40000
+    assert "compact_bound" in out["compact_bound_error"]

@@ -208,7 +208,7 @@ def test_large_synthetic_properties(oracle):
     st.add_dense(X, max_count=500, max_total=500)
     info = st.check()
     assert info["rows"] == N
-    uv = st.finalize()
+    uv = st.finalize(ragged=False)
     U = uv.Ui.view(K, uv.ldU)
     colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
     for lo in range(0, N, 500_000):
@@ -332,7 +332,7 @@ def test_rows_that_end_inside_a_vector_at_size(oracle):
     off = (-ws.data_ptr()) % 256
     _lib.check(L.dme_stats_dense_u16(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins,
                                      st.histV.data_ptr(), st.tbins, st.init_acc.data_ptr(),
-                                     st.status.data_ptr(), ws.data_ptr() + off, need,
+                                     st.status.data_ptr(), 0, ws.data_ptr() + off, need,
                                      torch.cuda.current_stream().cuda_stream))
     assert st.check()["rows"] == N
     ref = oracle.append_rows(X)
@@ -359,7 +359,7 @@ def test_rows_beyond_the_dense_range_go_through_csr(oracle, K, dtype):
     fn = L.dme_stats_dense_u16 if dtype == "u16" else L.dme_stats_dense_i32
     ws = torch.empty(L.dme_stats_workspace_bytes(N, K) + 256, dtype=torch.uint8, device="cuda")
     rc = fn(Xd.data_ptr(), N, K, K, st.hist.data_ptr(), st.nbins, st.histV.data_ptr(), st.tbins,
-            st.init_acc.data_ptr(), st.status.data_ptr(), ws.data_ptr() + (-ws.data_ptr()) % 256,
+            st.init_acc.data_ptr(), st.status.data_ptr(), 0, ws.data_ptr() + (-ws.data_ptr()) % 256,
             ws.numel() - 256, torch.cuda.current_stream().cuda_stream)
     assert rc == _lib.ERR_UNSUPPORTED
     st.add_dense(Xd)
@@ -423,7 +423,7 @@ def _csr_direct(dev, rowptr, colidx, vals, K, nbins, tbins, partitioned):
         ws, wsb = keep.data_ptr() + off, need
     _lib.check(L.dme_stats_csr_i32(rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), N, nnz, K,
                                    hist.data_ptr(), nbins, histV.data_ptr(), tbins, acc.data_ptr(),
-                                   status.data_ptr(), ws, wsb, torch.cuda.current_stream().cuda_stream))
+                                   status.data_ptr(), 0, ws, wsb, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     return hist, histV, acc, status
 
@@ -564,7 +564,7 @@ def _csr_direct_nnz(rowptr, colidx, vals, K, nbins, tbins, claimed_nnz):
     off = (-keep.data_ptr()) % 256
     _lib.check(L.dme_stats_csr_i32(rowptr.data_ptr(), colidx.data_ptr(), vals.data_ptr(), N, claimed_nnz, K,
                                    hist.data_ptr(), nbins, histV.data_ptr(), tbins, acc.data_ptr(),
-                                   status.data_ptr(), keep.data_ptr() + off, need,
+                                   status.data_ptr(), 0, keep.data_ptr() + off, need,
                                    torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     return hist, histV, acc, status
@@ -654,7 +654,7 @@ def test_more_rows_than_one_round_of_workgroups(K, N, max_total):
     st = dev.DeviceStats(K)
     st.add_dense(X, max_count=max_total, max_total=max_total)
     assert st.check()["rows"] == N
-    uv = st.finalize()
+    uv = st.finalize(ragged=False)
     U = uv.Ui.view(K, uv.ldU)
     colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
     step = max(1, (256 << 20) // K)
@@ -686,7 +686,7 @@ def test_long_rows_at_size_against_torch_reductions(K, N, dtype):
     st = dev.DeviceStats(K)
     st.add_dense(X, max_count=max_total, max_total=max_total)
     assert st.check()["rows"] == N
-    uv = st.finalize()
+    uv = st.finalize(ragged=False)
     U = uv.Ui.view(K, uv.ldU)
     colsum = torch.zeros(K, dtype=torch.int64, device="cuda")
     step = max(1, (64 << 20) // K)
