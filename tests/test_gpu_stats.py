@@ -872,7 +872,10 @@ def test_bounds_pass(dtype, N, K, pad):
         st.add_dense(Xd)
         info = st.check()
         assert info["max_count"] == int(pos.max()) and info["max_total"] == int(pos.sum(axis=1).max())
-        assert st.nbins == int(pos.max()) + 1 and st.tbins == int(pos.sum(axis=1).max()) + 1
+        # (the dense bins stop at max(64, 2^25 // K); beyond them the overflow store takes over)
+        assert st.nbins == min(int(pos.max()) + 1, st.dense_bins)
+        assert (st.overflow is not None) == (int(pos.max()) + 1 > st.dense_bins)
+        assert st.tbins == int(pos.sum(axis=1).max()) + 1
 
 
 def test_bounds_pass_csr():
