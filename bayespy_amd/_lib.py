@@ -85,6 +85,9 @@ SIGNATURES = {
     "dme_solve_set_path": (_int, [_int]),
     "dme_parse_count_rows": (_i64, [ctypes.c_char_p, _i64]),
     "dme_parse_counts": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _int]),
+    "dme_parse_counts_selected": (_int, [ctypes.c_char_p, _i64, _int, _i64, _vp, _i64, _vp, _i64, _vp, _int]),
+    "dme_cap_draws_needed": (_i64, [_vp, _i64, _i64, _i64]),
+    "dme_sample_and_cap_i32": (_int, [_vp, _i64, _i64, _f64, _i64, _vp, _i64, _vp, _vp]),
     "dme_eval_cpt": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _f64, _int, _vp, _vp, _vp,
                             _vp, _i64, _vp]),
     "dme_solve_cpt": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _f64, _int, _vp,

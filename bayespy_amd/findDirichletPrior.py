@@ -6,9 +6,12 @@ of maxsklar/BayesPy, plus the NumPy port's -d/--delimiter (NumpyPort/findDirichl
 
     cat test.csv | ./findDirichletPrior.py --sampleRate 1
 
-Rows are parsed on the host exactly as the reference does (csv.reader, int()), then handed to the
-GPU as one matrix: the statistics pass, the suffix scan, the CLI's initial-alpha formula
-(DE/fdp.py:87-89, 104-108) and the whole Newton loop run in HIP kernels.
+stdin is parsed in pieces by libdme_hip's multi-threaded parser (text outside its strict grammar
+goes through the reference's own csv.reader + int() loop), each piece handed to the GPU as one
+matrix: the statistics pass, the suffix scan, the CLI's initial-alpha formula (DE/fdp.py:87-89,
+104-108) and the whole Newton loop run in HIP kernels.  -s and -M keep the reference's semantics and
+its use of Python's `random` stream draw for draw (DE/fdp.py:78, :85), so a seeded run selects and
+thins the same rows on both paths.
 """
 import os
 import sys
@@ -29,9 +32,10 @@ from . import dirichletMultinomialEstimation as DME
 from . import samplingTools as Sample
 
 
-def _parse_fast(raw, delimiter, K):
+def _parse_fast(raw, delimiter, K, keep=None):
     """N x K int32 matrix from delimiter-separated text via dme_parse_counts, or None when the text
-    is outside the fast parser's grammar (the caller then runs the reference's row loop)."""
+    is outside the fast parser's grammar (the caller then runs the reference's row loop).
+    keep (uint8 per line): only those lines are parsed (dme_parse_counts_selected)."""
     import ctypes
 
     from . import _lib
@@ -40,12 +44,19 @@ def _parse_fast(raw, delimiter, K):
     if not raw or ord(delimiter) >= 128:
         return None
     L = _lib.lib()
-    n = L.dme_parse_count_rows(raw, len(raw))
+    n = L.dme_parse_count_rows(raw, len(raw)) if keep is None else int(np.count_nonzero(keep))
     out = np.empty((max(n, 1), K), dtype=np.int32)
     got = ctypes.c_int64(0)
-    rc = L.dme_parse_counts(raw, len(raw), ord(delimiter), K, out.ctypes.data, n,
-                            ctypes.addressof(got), min(os.cpu_count() or 1, 16))
-    if rc != 0 or got.value != n or n == 0:
+    threads = min(os.cpu_count() or 1, 16)
+    if keep is None:
+        rc = L.dme_parse_counts(raw, len(raw), ord(delimiter), K, out.ctypes.data, n,
+                                ctypes.addressof(got), threads)
+        if n == 0:
+            return None
+    else:
+        rc = L.dme_parse_counts_selected(raw, len(raw), ord(delimiter), K, keep.ctypes.data, keep.size,
+                                         out.ctypes.data, n, ctypes.addressof(got), threads)
+    if rc != 0 or got.value != n:
         return None
     return out[:n]
 
@@ -72,18 +83,114 @@ def _row_loop(lines, dataObj, K, sampleRate, M, delimiter, idx):
     return idx
 
 
+class _Stream:
+    """Python's global `random` stream, many draws at a time.  random.random() is MT19937 with the
+    53-bit construction (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53, which is also what numpy's legacy
+    RandomState.random_sample computes: a RandomState loaded with random.getstate() yields the very
+    doubles the next calls of random.random() would, a million of them in milliseconds, and its end
+    state goes back into `random`.  Checked against random.random() itself on first use; if the two
+    ever disagreed (another generator behind `random`), draws fall back to one call each."""
+
+    _bulk_ok = None
+
+    @classmethod
+    def _rs(cls):
+        st = random.getstate()
+        if st[0] != 3 or len(st[1]) != 625:
+            return None, st
+        rs = np.random.RandomState()
+        rs.set_state(("MT19937", np.array(st[1][:-1], dtype=np.uint32), int(st[1][-1])))
+        return rs, st
+
+    @classmethod
+    def _check(cls):
+        if cls._bulk_ok is None:
+            saved = random.getstate()
+            try:
+                rs, _ = cls._rs()
+                ok = rs is not None
+                if ok:
+                    want = [random.random() for _ in range(700)]  # crosses a state regeneration
+                    ok = rs.random_sample(700).tolist() == want
+                cls._bulk_ok = bool(ok)
+            finally:
+                random.setstate(saved)
+        return cls._bulk_ok
+
+    @classmethod
+    def peek(cls, n):
+        """The next n draws WITHOUT consuming them (None when bulk draws are unavailable)."""
+        if not cls._check():
+            return None
+        rs, _ = cls._rs()
+        return rs.random_sample(int(n))
+
+    @classmethod
+    def advance(cls, n):
+        """Consumes n draws."""
+        rs, st = cls._rs()
+        rs.random_sample(int(n))
+        ns = rs.get_state()
+        random.setstate((st[0], tuple(int(x) for x in ns[1]) + (int(ns[2]),), st[2]))
+
+    @classmethod
+    def take(cls, n):
+        """The next n draws, consumed."""
+        u = cls.peek(n)
+        if u is None:
+            return np.fromiter((random.random() for _ in range(n)), dtype=np.float64, count=n)
+        cls.advance(n)
+        return u
+
+
+def _select_and_cap(X, sampleRate, M):
+    """-s and -M on a parsed piece, with the reference's own draws in the reference's own order
+    (DE/fdp.py:78 `if random.random() < sampleRate` once per row, then DE/fdp.py:85
+    `while sum(counts) > M: counts[drawCategory(counts)] -= 1` for a kept row, before the next row's
+    draw): seeded with random.seed(), the fast path keeps and thins exactly the rows the row loop
+    would.  Returns the kept rows as a matrix (rows above the cap thinned; X is reused)."""
+    import ctypes
+
+    from . import _lib
+    n, K = X.shape
+    L = _lib.lib()
+    cap = min(int(M), 2**62)
+    need = L.dme_cap_draws_needed(X.ctypes.data, n, K, cap)
+    u = _Stream.peek(need)
+    if u is not None:
+        kept, used = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.check(L.dme_sample_and_cap_i32(X.ctypes.data, n, K, float(sampleRate), cap, u.ctypes.data,
+                                            u.size, ctypes.addressof(kept), ctypes.addressof(used)))
+        _Stream.advance(used.value)
+        return X[:kept.value]
+    # no bulk draws: the loop itself, draw by draw
+    keep = np.empty(n, dtype=bool)
+    over = (X.sum(axis=1, dtype=np.int64) > M).tolist()
+    for i in range(n):
+        k = random.random() < sampleRate
+        keep[i] = k
+        if k and over[i]:
+            counts = X[i].tolist()
+            while sum(counts) > M:
+                counts[Sample.drawCategory(counts)] -= 1
+            X[i] = counts
+    return X[keep]
+
+
 def load_data(stdin, K, sampleRate, M, delimiter):
     """The load loop of DE/fdp.py:66-93 -> (CompressedRowData, rows read)."""
     csv.field_size_limit(1000000000)
     logging.debug("Loading data")
     dataObj = DME.CompressedRowData(K)
 
-    # Fast path (libdme_hip's multi-threaded parser): every row is kept (-s 1) and uncapped (no -M),
-    # so no per-row random draw decides anything.  stdin is read in pieces that end on a line
-    # break; each piece is parsed, counted on the GPU and dropped, so memory stays bounded whatever
-    # the input size.  From the first piece outside the parser's strict grammar onwards the
-    # reference's own loop takes over (it keeps the reference's error behaviour).
-    fast = sampleRate >= 1.0 and M == sys.maxsize and len(delimiter) == 1
+    # Fast path (libdme_hip's multi-threaded parser).  stdin is read in pieces that end on a line
+    # break; each piece is parsed, sampled / capped (-s, -M: _select_and_cap), counted on the GPU and
+    # dropped, so memory stays bounded whatever the input size.  With -s 1 and no -M no draw decides
+    # anything and none is made.  From the first piece outside the parser's strict grammar onwards
+    # the reference's own loop takes over (it keeps the reference's error behaviour, and continues
+    # the same random stream).
+    fast = len(delimiter) == 1
+    plain = sampleRate >= 1.0 and M == sys.maxsize
     if not fast:
         return dataObj, _row_loop(stdin, dataObj, K, sampleRate, M, delimiter, 0)
 
@@ -104,8 +211,18 @@ def load_data(stdin, K, sampleRate, M, delimiter):
         else:
             carry = piece[:0]
         if piece:
-            X = _parse_fast(piece, delimiter, K)
+            keep = None
+            if sampleRate < 1.0 and M == sys.maxsize:
+                # -s alone: one draw per line decides, before any field is looked at (DE/fdp.py:78-79)
+                from . import _lib
+                raw_piece = piece if binary else piece.encode()
+                n_lines = _lib.lib().dme_parse_count_rows(raw_piece, len(raw_piece))
+                saved = random.getstate()
+                keep = (_Stream.take(n_lines) < sampleRate).astype(np.uint8)
+            X = _parse_fast(piece, delimiter, K, keep)
             if X is None:
+                if keep is not None:
+                    random.setstate(saved)  # the row loop below makes this piece's draws itself
                 # hand this piece and everything after it to the reference's loop
                 import io
                 import itertools
@@ -115,10 +232,13 @@ def load_data(stdin, K, sampleRate, M, delimiter):
                 lines = itertools.chain(text.splitlines(True), _lines_after(rest, tail))
                 return dataObj, _row_loop(lines, dataObj, K, sampleRate, M, delimiter, idx)
             before = idx
-            idx += X.shape[0]
+            idx += X.shape[0] if keep is None else keep.size
             for done in range((before // 1000000 + 1) * 1000000, idx + 1, 1000000):
                 logging.debug("Loading Data: %s rows done" % done)
-            dataObj.appendMatrix(X)
+            if not plain and keep is None:
+                X = _select_and_cap(X, sampleRate, M)
+            if X.shape[0]:
+                dataObj.appendMatrix(X)
         if not block:
             break
     return dataObj, idx

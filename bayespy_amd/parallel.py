@@ -146,7 +146,10 @@ def _sync_for_gloo(t, group):
     """Rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor was seen
     to hang when issued behind a long-running kernel of the same process; RCCL ("nccl") orders
     itself on the stream and needs no host sync."""
+    import os
     import torch.distributed as dist
+    if os.environ.get("DME_GLOO_NOSYNC"):  # (diagnosis of the hang described above)
+        return
     if t.is_cuda and dist.get_backend(group) == "gloo":
         torch.cuda.current_stream(t.device).synchronize()
 

@@ -58,6 +58,12 @@ def parse():
     ap.add_argument("--dtype", choices=["u16", "i32"], default="u16")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-port-rows", type=int, default=20_000,
+                    help="rows the CPython-loop port is timed on (SURVEY 8d: 20 000 rows x 3, median)")
+    ap.add_argument("--cpu-numpy-port-rows", type=int, default=5_000,
+                    help="rows the NumPy-structured port is timed on, x 3, median (it runs at ~1.5e3 "
+                         "rows/s: 20 000 rows x 3 would add 40 s to every bench run)")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals "
@@ -75,6 +81,23 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="check size-independent properties of the statistics after the run")
     return ap.parse_args()
+
+
+def git_blob_sha1(path):
+    """The git blob id of a file (sha1 of "blob <size>\\0" + content), computed without git."""
+    import hashlib
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def median_time(fn, repeats):
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
 
 
 def launch_ranks(args):
@@ -280,17 +303,27 @@ def main():
 
     algo_bytes = N * K * esize  # this GPU's block of the count matrix, read exactly once
     achieved = algo_bytes / (stats_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, benchmarks/pmc_bench_traffic.sh -> profiles/traffic.json).  The file names the git blob of
+    # the kernel source it was measured on: a tree whose dme_stats.hip differs reports null, not a stale
+    # number.
+    traffic, traffic_note = None, "profiles/traffic.json absent"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            # PMC traffic is per launch of the profiled shape only
-            if tj.get("N") == N and tj.get("K") == K:
+            blob = git_blob_sha1(os.path.join(ROOT, "bayespy_amd", "csrc", "dme_stats.hip"))
+            if tj.get("dme_stats_hip_blob") != blob:
+                traffic_note = ("profiles/traffic.json was measured on dme_stats.hip blob %s, this tree "
+                                "holds %s" % (tj.get("dme_stats_hip_blob"), blob))
+            elif tj.get("N") != N or tj.get("K") != K:
+                traffic_note = "profiles/traffic.json is for N=%s K=%s" % (tj.get("N"), tj.get("K"))
+            else:  # PMC traffic is per launch of the profiled shape only
                 traffic = tj.get(f"stats_dense_{args.dtype}_bytes_per_launch")
-        except Exception:
-            traffic = None
+                traffic_note = "PMC FETCH_SIZE/WRITE_SIZE, commit %s" % tj.get("commit")
+        except Exception as ex:
+            traffic, traffic_note = None, "profiles/traffic.json unreadable: %s" % ex
 
     line = {
         "metric": "count-rows/sec to converged Dirichlet MLE (K=1000, 10M rows) at 1/2/4/8 GPUs",
@@ -318,7 +351,8 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "stats_dense_kernel", "achieved": achieved,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
+            "traffic": traffic, "traffic_source": traffic_note,
+            "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": stats_ms, "per": "GPU (rank 0)",
         },
         "phases_ms": {
@@ -358,9 +392,8 @@ def main():
         oracle.build()
         ns = min(args.cpu_sample_rows, N)
         Xh = X[:ns].cpu().numpy()
-        t0 = time.perf_counter()
-        oracle.append_rows(Xh, capU=M, capV=M)
-        t_stats_cpu = time.perf_counter() - t0
+        t_stats_cpu, all_c = median_time(lambda: oracle.append_rows(Xh, capU=M, capV=M),
+                                         max(args.cpu_repeats, 1))
         # the solver's cost does not depend on N: time it on the full-size statistics
         Ufull, Vfull = uv.to_lists()
         full = oracle.stats_from_lists(Ufull, Vfull)
@@ -381,7 +414,7 @@ def main():
         line["cpu_baseline"] = {
             "value": N / cpu_total, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": ("oracle/dme_oracle.c (single-threaded C port of appendRow + mean accumulator) "
-                       "timed on the first %d rows: %.2f s, EXTRAPOLATED linearly to %d rows; plus the "
+                       "timed on the first %d rows x 3 runs: median %.2f s, EXTRAPOLATED linearly to %d rows; plus the "
                        "oracle solver on the full-size U/V: %.3f s (%d iterations, %d loss evals)"
                        % (ns, t_stats_cpu, N, t_solve_cpu, sol["n_iters"], sol["n_evals"])),
             "host_cpus": os.cpu_count(), "cpu_model": cpu_model,
@@ -389,23 +422,24 @@ def main():
         # the reference's own cost models — interpreted loops per row (DE) and ndarray slices grown by
         # np.append per column per row (NumPy port) — on smaller samples, statistics build only
         from oracle import np_port, py_port
-        npy = min(2000, ns)
+        reps = max(args.cpu_repeats, 1)
+        npy = min(args.cpu_port_rows, ns)
         rows_py = Xh[:npy].astype(np.int64).tolist()
-        t0 = time.perf_counter()
-        py_port.build(rows_py, K)
-        t_py = time.perf_counter() - t0
+        t_py, all_py = median_time(lambda: py_port.build(rows_py, K), reps)
         line["cpu_baseline"]["cpython_port"] = {
             "value": npy / t_py, "unit": "rows/s", "cores": 1,
             "sample": "oracle/py_port.py (CPython loops of DE/dme.py:113-123 + DE/fdp.py:87-89) on "
-                      "%d rows: %.2f s; statistics build only; rows/s holds for any N (O(N))" % (npy, t_py)}
-        t0 = time.perf_counter()
-        np_port.build(rows_py, K)
-        t_np = time.perf_counter() - t0
+                      "%d rows x %d runs, median %.2f s (%s); statistics build only; rows/s holds for "
+                      "any N (O(N))" % (npy, reps, t_py, ", ".join("%.2f" % t for t in all_py))}
+        nnp = min(args.cpu_numpy_port_rows, ns)
+        rows_np = rows_py[:nnp]
+        t_np, all_np = median_time(lambda: np_port.build(rows_np, K), reps)
         line["cpu_baseline"]["numpy_port"] = {
-            "value": npy / t_np, "unit": "rows/s", "cores": 1,
+            "value": nnp / t_np, "unit": "rows/s", "cores": 1,
             "sample": "oracle/np_port.py (ndarray U/V grown by np.append, a slice add per column per "
                       "row: NumpyPort/dirichletMultinomialEstimation.py:106-121, + DE/fdp.py:87-89) on "
-                      "%d rows: %.2f s; statistics build only; rows/s holds for any N (O(N))" % (npy, t_np)}
+                      "%d rows x %d runs, median %.2f s (%s); statistics build only; rows/s holds for "
+                      "any N (O(N))" % (nnp, reps, t_np, ", ".join("%.2f" % t for t in all_np))}
         rel = float(np.max(np.abs(out["alpha"] - sol["alpha"]) / np.abs(sol["alpha"])))
         ref_loss = oracle.total_loss(sol["alpha"], full, 0.0)
         rel_loss = abs(out["final_loss"] - ref_loss) / abs(ref_loss)

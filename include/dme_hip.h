@@ -507,6 +507,27 @@ int64_t dme_parse_count_rows(const char* text /*[host]*/, int64_t nbytes);
 int dme_parse_counts(const char* text /*[host]*/, int64_t nbytes, int delimiter, int64_t K,
                      int32_t* out /*[host]*/, int64_t out_rows, int64_t* n_rows /*[host]*/,
                      int nthreads);
+/* The CLI's -s (DE/fdp.py:78: a row is kept when random.random() < sampleRate, and only a kept row's
+ * fields are converted, :79) and -M (DE/fdp.py:85: `while sum(counts) > M: counts[drawCategory(counts)]
+ * -= 1`, DE/samplingTools.py:49-58) on top of the fast parser, with the reference's draws in the
+ * reference's order - the caller supplies them from Python's own `random` stream (bulk draws of the same
+ * MT19937 state), so a seeded run keeps and thins the very rows the reference does.
+ *   dme_parse_counts_selected  parses only the lines with keep[i] != 0 (n_keep = the text's line count),
+ *                      written back to back; the other lines are skipped unparsed, as the reference
+ *                      never looks at them either.  For -s without -M: the draws are one per line.
+ *   dme_cap_draws_needed  n + sum_i max(0, sum(row_i) - M): the draws rows X could take at most.
+ *   dme_sample_and_cap_i32  rows X [n][K] in place: row i takes u[p++] (kept iff < sample_rate) and, if
+ *                      kept, one draw per decrement while its total exceeds M; kept rows move to the
+ *                      front.  *n_kept rows remain, *n_used draws were taken (the caller advances its
+ *                      stream by that many). */
+int dme_parse_counts_selected(const char* text /*[host]*/, int64_t nbytes, int delimiter, int64_t K,
+                              const uint8_t* keep /*[host][n_keep]*/, int64_t n_keep,
+                              int32_t* out /*[host]*/, int64_t out_rows, int64_t* n_rows /*[host]*/,
+                              int nthreads);
+int64_t dme_cap_draws_needed(const int32_t* X /*[host][n][K]*/, int64_t n, int64_t K, int64_t M);
+int dme_sample_and_cap_i32(int32_t* X /*[host][n][K]*/, int64_t n, int64_t K, double sample_rate,
+                           int64_t M, const double* u /*[host][n_u]*/, int64_t n_u,
+                           int64_t* n_kept /*[host]*/, int64_t* n_used /*[host]*/);
 
 /* ---------------------------------------------------------------------------------------------
  * Synthetic count rows for benchmarks and tests (no reference counterpart: the reference's

@@ -170,6 +170,37 @@ def test_cli_row_cap_and_sampling_paths():
     assert all(abs(s - f) / f < 0.5 for s, f in zip(sampled, full))
 
 
+def test_cli_sampling_and_row_cap_match_the_seeded_reference():
+    """-s and -M draw from Python's global `random` stream (DE/fdp.py:78, :85).  With the stream
+    seeded, the fast path (parsed pieces, _select_and_cap) and the row loop (text outside the fast
+    grammar) keep and thin exactly the rows the reference CLI did - tests/golden/cli_sampling.json,
+    produced by running the reference CLI itself with the same seed: identical U / V, the printed
+    priors to 1e-9, and the stream left in the same state."""
+    import json, os, random
+    from conftest import GOLDEN
+    from bayespy_amd import findDirichletPrior as cli
+    fx = load_golden("test_csv")
+    plain = _rows_text(fx)
+    quoted = "".join('"%d"\t%d\n' % (r[0], r[1]) for r in fx["X"])
+    with open(os.path.join(GOLDEN, "cli_sampling.json")) as f:
+        cases = json.load(f)["cases"]
+    assert any("-s" in c["argv"] and "-M" in c["argv"] for c in cases)
+    for c in cases:
+        opt = dict(zip(c["argv"][::2], c["argv"][1::2]))
+        s_rate, M = float(opt.get("-s", "1")), int(opt.get("-M", sys.maxsize))
+        states = []
+        for text in (plain, quoted):
+            random.seed(c["seed"])
+            data, n_read = cli.load_data(io.StringIO(text), 2, s_rate, M, "\t")
+            states.append(random.getstate())
+            assert n_read == fx["N"]
+            assert data.U == c["U"] and data.V == c["V"], (c["argv"], "quoted" if text is quoted else "fast")
+            random.seed(c["seed"])
+            got = _run_cli(c["argv"] + ["-L", "ERROR"], text)
+            np.testing.assert_allclose(got, c["priors"], rtol=1e-9)
+        assert states[0] == states[1]
+
+
 def test_weighted_rows_match_reference():
     """appendRow(row, w) with fractional / zero / unit weights mixed, as the reference's mixture EM
     feeds it (CPT/dirichletMixtureEstimation.py:129-133): U/V within 1e-12 (fp64 sums in another
