@@ -143,12 +143,32 @@ def allreduce_stats_tensors(hist, histV, status, init_acc, K, nbins, tbins, grou
 
 
 def _sync_for_gloo(t, group):
-    """Rehearsals with several gloo ranks on one card: gloo's staged copy of a device tensor was seen
-    to hang when issued behind a long-running kernel of the same process; RCCL ("nccl") orders
-    itself on the stream and needs no host sync."""
+    """gloo only (CPU tests never reach it; rehearsals of bench.py with gloo ranks on a GPU do): drain
+    the current stream before handing gloo a device tensor.
+
+    What is known (round 3, reproduced on an MI355X box with DME_GLOO_NOSYNC=1 under bench.py's
+    watchdog; profiles/r3_notes.md):
+      * without this wait the process blocks for good inside dist.all_reduce -> ProcessGroupGloo's
+        work.wait(), also with ONE rank (so it is not two processes sharing a card), and only when
+        steps are enqueued back to back: the step whose all-reduce hangs finds the previous step's
+        solver launches and its 128-byte copy to pinned memory still queued on the current stream.
+        A step that starts on a drained stream (warm-up, `--sync-steps`) goes through, and so do small
+        inputs, whose kernels finish before the host arrives (100 000 rows: fine; 4 M rows: hangs);
+      * gloo does not run on our stream: ProcessGroupGloo records an event on the current stream
+        (behind the pack kernel), makes a stream of ITS OWN from torch's high-priority pool wait for
+        it, copies the tensor to pinned host memory there, and a worker thread blocks in that stream's
+        synchronize before the CPU reduction (ProcessGroupGloo.cpp: initializeStreamsEvents /
+        AsyncAllreduceCUDAWork).  The wait that never returns is that side stream's: a cross-stream
+        event wait issued while the recording stream is still busy.  Why the ROCm runtime does not
+        resolve it here is not established; the pack kernel, the message and the collective's
+        arguments are the same ones the RCCL path uses;
+      * RCCL ("nccl") needs no host wait and has none: ProcessGroupNCCL enqueues the collective on its
+        own stream behind the same kind of event and no host thread waits on it -
+        tests/test_gpu_distributed.py::test_rccl_code_path_with_one_rank runs three estimations in
+        flight through it, in every message form."""
     import os
     import torch.distributed as dist
-    if os.environ.get("DME_GLOO_NOSYNC"):  # (diagnosis of the hang described above)
+    if os.environ.get("DME_GLOO_NOSYNC"):  # (the diagnosis above)
         return
     if t.is_cuda and dist.get_backend(group) == "gloo":
         torch.cuda.current_stream(t.device).synchronize()
