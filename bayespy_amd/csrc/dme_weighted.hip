@@ -89,27 +89,35 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
             return p ? p[c] : dme_readlane_f64(v, (int)c);
         }
     };
+    // The row-total bins take the C weights in ONE LDS instruction: lane c adds weight c (the lane that
+    // holds it anyway) - five single-lane adds before.  The largest total is wave-uniform: a register.
+    u64 maxt_seen = 0;
     auto total_of = [&](u64 total, const Wts& w) {
         if (total > 0) {  // wave-uniform
             if ((long long)total < a.tbins) {
-                if (lane == 0) atomicMax(&sh_stat[5], total);
-                for (long long c = 0; c < C; ++c) {
-                    const double wc = w[c];
-                    if (lane == 0) {
-                        if (total < (u64)TB) atomicAdd(&hv[c * TB + (long long)total], wc);
-                        else atomicAdd(&a.histVW[c * a.tbins + (long long)total], wc);
-                    }
+                maxt_seen = total > maxt_seen ? total : maxt_seen;
+                if (lane < C) {
+                    const double wc = w.p ? w.p[lane] : w.v;
+                    if (total < (u64)TB) atomicAdd(&hv[lane * TB + (long long)total], wc);
+                    else atomicAdd(&a.histVW[lane * a.tbins + (long long)total], wc);
                 }
             } else if (lane == 0) {
                 bad_rows++;
             }
         }
     };
-    auto cell = [&](int v, long long k, const Wts& w) {
+    // J > 0: a lane's columns are fixed (lane + 64 j), so their largest counts live in registers and
+    // reach LDS once, at the end - an LDS atomic max per non-zero cell before.
+    u32 mxr[JR];
+#pragma unroll
+    for (int j = 0; j < JR; ++j) mxr[j] = 0;
+    auto cell = [&](int v, long long k, const Wts& w, u32* mreg) {
         if (v == 0) return;
         if (v < 0) { neg++; return; }
         if ((long long)v >= a.nbins) { bad_cells++; return; }
-        if (a.mxlds) {
+        if (mreg) {
+            *mreg = (u32)v > *mreg ? (u32)v : *mreg;
+        } else if (a.mxlds) {
             atomicMax(&mx[k], (u32)v);
         } else if (__builtin_nontemporal_load(&a.maxcol[k]) < (long long)v) {
             atomicMax((u64*)&a.maxcol[k], (u64)v);  // the maxima settle after a few rows
@@ -125,29 +133,54 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
     }
     for (long long i0 = row0 + wave; i0 < row1; i0 += (long long)WWAVES * DEPTH) {
         if constexpr (J > 0) {
+            // The DEPTH rows in hand first give up their cells and row totals - DEPTH independent DPP
+            // reductions side by side - and their buffers are refilled; only then do the LDS adds of the
+            // rows follow one another (with one row at a time the wave sat through a reduction's whole
+            // dependent chain before every row's adds: 4 waves per SIMD do not hide that).
+            int cur[DEPTH][JR];
+            double wcur[DEPTH];
+            u64 tot[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const long long i = i0 + (long long)d * WWAVES;
+#pragma unroll
+                for (int j = 0; j < J; ++j) cur[d][j] = rowbuf[d][j];
+                wcur[d] = wbuf[d];
+                load_row(rowbuf[d], wbuf[d], i + (long long)WWAVES * DEPTH);
+            }
+            u32 m = 0;
+            u32 s32[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                s32[d] = 0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const u32 pos = cur[d][j] > 0 ? (u32)cur[d][j] : 0u;
+                    m |= pos;
+                    s32[d] += pos;
+                }
+            }
+            // 64 lanes x J cells below 2^20 cannot wrap 32 bits: the DPP sums
+            if (__builtin_expect(!__any(m >= (1u << 20)), 1)) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) tot[d] = (u64)dme_wave_sum_u32(s32[d]);
+            } else {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    u64 s = 0;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) s += (u64)(cur[d][j] > 0 ? cur[d][j] : 0);
+                    tot[d] = dme_wave_sum_u64(s);
+                }
+            }
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const long long i = i0 + (long long)d * WWAVES;
                 if (i < row1) {  // wave-uniform
-                    int cur[JR];
+                    const Wts w{nullptr, wcur[d]};
+                    total_of(tot[d], w);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) cur[j] = rowbuf[d][j];
-                    const Wts w{nullptr, wbuf[d]};
-                    load_row(rowbuf[d], wbuf[d], i + (long long)WWAVES * DEPTH);
-                    u32 m = 0;
-                    u64 s = 0;
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        const u32 pos = cur[j] > 0 ? (u32)cur[j] : 0u;
-                        m |= pos;
-                        s += pos;
-                    }
-                    // 64 lanes x J cells below 2^20 cannot wrap 32 bits: the DPP sum
-                    const u64 total = __any(m >= (1u << 20)) ? dme_wave_sum_u64(s)
-                                                            : (u64)dme_wave_sum_u32((u32)s);
-                    total_of(total, w);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) cell(cur[j], lane + 64 * j, w);
+                    for (int j = 0; j < J; ++j) cell(cur[d][j], lane + 64 * j, w, &mxr[j]);
                 }
             }
         } else {
@@ -160,12 +193,23 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
                 s += (u64)(v > 0 ? v : 0);
             }
             total_of(dme_wave_sum_u64(s), w);
-            for (long long k = lane; k < K; k += 64) cell(row[k], k, w);  // second read: L1 / L2
+            for (long long k = lane; k < K; k += 64) cell(row[k], k, w, nullptr);  // second read: L1 / L2
         }
     }
     bad_cells = dme_wave_sum_u64(bad_cells);
     bad_rows = dme_wave_sum_u64(bad_rows);
     neg = dme_wave_sum_u64(neg);
+    if constexpr (J > 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const long long k = lane + 64 * j;
+            if (mxr[j] && k < K) {
+                if (a.mxlds) atomicMax(&mx[k], mxr[j]);
+                else if (a.maxcol[k] < (long long)mxr[j]) atomicMax((u64*)&a.maxcol[k], (u64)mxr[j]);
+            }
+        }
+    }
+    if (lane == 0 && maxt_seen) atomicMax(&sh_stat[5], maxt_seen);
     if (lane == 0) {
         if (bad_cells) atomicAdd(&sh_stat[1], bad_cells);
         if (bad_rows) atomicAdd(&sh_stat[2], bad_rows);
