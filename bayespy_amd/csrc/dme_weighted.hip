@@ -15,6 +15,8 @@
 // bins were privatised).  C weight columns per row (the C components of the mixture EM,
 // CPT/dirichletMixtureEstimation.py:130-133) fill C histograms in the same pass over X.
 // fp64 sums here depend on arrival order in the last bits (the reference adds row by row).
+#include <type_traits>
+
 #include "dme_common.h"
 
 namespace {
@@ -34,6 +36,11 @@ struct WArgs {
     long long* maxcol;
     long long* maxtot;
     u64* status;
+    int KP;      // doubles from one LDS bin row to the next: K rounded up to a multiple of 32 (256 bytes =
+                 // all LDS banks), so that a lane's bank depends on its column alone - a wave's lanes,
+                 // which own distinct consecutive columns, then hit the banks like a linear access
+                 // whatever their counts (ds_add_f64: 8 cycles per wave instruction against 25 for
+                 // random addresses, profiles/r3_lds_atomics_microbench.txt)
     int B;       // counts 1..B live in LDS
     int TB;      // totals below TB live in LDS
     int mxlds;   // column maxima in LDS (K small enough)
@@ -42,18 +49,22 @@ struct WArgs {
 
 // J > 0: a lane keeps its J cells of a row (columns lane + 64 j) in registers and the next row's
 // loads are in flight while the current row is processed; J == 0 (K > 1024): the row is read twice.
-template <int J>
+// CC > 0: the number of weight columns is known at compile time (1 ... 8: a mixture's components), so
+// the C adds of a cell are straight-line code - one address, C ds_add_f64 at fixed distances - instead of
+// a scalar loop with a branch per weight (108 scalar instructions per row of K = 100 before).
+template <int J, int CC>
 __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
     extern __shared__ double wl[];
-    const long long K = a.K, C = a.C;
+    const long long K = a.K, C = CC > 0 ? CC : a.C;
     const int B = a.B, TB = a.TB;
     double* hv = wl;                              // [C][TB]
-    double* h = hv + C * TB;                      // [C][B][K]: count v of column k at ((c*B + v-1)*K + k)
-    u32* mx = (u32*)(h + C * (long long)B * K);   // [K] when mxlds
+    const long long KP = a.KP;
+    double* h = hv + C * TB;                      // [C][B][KP]: count v of column k at ((c*B + v-1)*KP + k)
+    u32* mx = (u32*)(h + C * (long long)B * KP);  // [K] when mxlds
     __shared__ u64 sh_stat[8];  // [1] cells >= nbins [2] totals >= tbins [3] negatives [5] max total
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long nd = C * TB + C * (long long)B * K;
+    const long long nd = C * TB + C * (long long)B * KP;
     for (long long i = tid; i < nd; i += WBLOCK) wl[i] = 0.0;
     if (a.mxlds)
         for (long long k = tid; k < K; k += WBLOCK) mx[k] = 0;
@@ -111,10 +122,15 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
     u32 mxr[JR];
 #pragma unroll
     for (int j = 0; j < JR; ++j) mxr[j] = 0;
-    auto cell = [&](int v, long long k, const Wts& w, u32* mreg) {
-        if (v == 0) return;
-        if (v < 0) { neg++; return; }
-        if ((long long)v >= a.nbins) { bad_cells++; return; }
+    // A cell is classified first (zero / negative / beyond the histogram / counted: its column maximum
+    // noted), then its C weights are added.  The weights reach the adds as wave-uniform scalars that
+    // the caller read off their lanes in UNIFORM control flow: reading them behind the divergent
+    // `v == 0` test went wrong once registers ran short - a value reloaded from scratch under a partial
+    // exec mask is stale in the lanes that are off, and v_readlane reads those lanes too.
+    auto classify = [&](int v, long long k, u32* mreg) -> bool {
+        if (v == 0) return false;
+        if (v < 0) { neg++; return false; }
+        if ((long long)v >= a.nbins) { bad_cells++; return false; }
         if (mreg) {
             *mreg = (u32)v > *mreg ? (u32)v : *mreg;
         } else if (a.mxlds) {
@@ -122,10 +138,31 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
         } else if (__builtin_nontemporal_load(&a.maxcol[k]) < (long long)v) {
             atomicMax((u64*)&a.maxcol[k], (u64)v);  // the maxima settle after a few rows
         }
+        return true;
+    };
+    auto add_one = [&](int v, long long k, long long c, double wc) {
+        // (the LDS add through an explicit LDS pointer: left as two generic atomics, the compiler folded
+        // the branches into one flat atomic on a selected pointer and its address-space test did not
+        // assemble - "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base")
+        typedef __attribute__((address_space(3))) double lds_double;
         if (v <= B)
-            for (long long c = 0; c < C; ++c) atomicAdd(&h[(c * B + (v - 1)) * K + k], w[c]);
+            __hip_atomic_fetch_add((lds_double*)&h[(c * B + (v - 1)) * KP + k], wc, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         else
-            for (long long c = 0; c < C; ++c) atomicAdd(&a.histW[(c * K + k) * a.nbins + v], w[c]);
+            atomicAdd(&a.histW[(c * K + k) * a.nbins + v], wc);
+    };
+    auto add_fixed = [&](int v, long long k, const double* wsc) {  // CC > 0: straight-line code
+        if (v <= B) {
+            double* cellp = &h[(long long)(v - 1) * KP + k];
+            const long long cstride = (long long)B * KP;
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                __hip_atomic_fetch_add((__attribute__((address_space(3))) double*)(cellp + c * cstride), wsc[c],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CC; ++c) atomicAdd(&a.histW[((long long)c * K + k) * a.nbins + v], wsc[c]);
+        }
     };
     if constexpr (J > 0) {
 #pragma unroll
@@ -179,8 +216,24 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
                 if (i < row1) {  // wave-uniform
                     const Wts w{nullptr, wcur[d]};
                     total_of(tot[d], w);
+                    bool ok[J];
 #pragma unroll
-                    for (int j = 0; j < J; ++j) cell(cur[d][j], lane + 64 * j, w, &mxr[j]);
+                    for (int j = 0; j < J; ++j) ok[j] = classify(cur[d][j], lane + 64 * j, &mxr[j]);
+                    if constexpr (CC > 0) {
+                        double wsc[CC];
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) wsc[c] = dme_readlane_f64(wcur[d], c);
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            if (ok[j]) add_fixed(cur[d][j], lane + 64 * j, wsc);
+                    } else {
+                        for (long long c = 0; c < C; ++c) {
+                            const double wc = dme_readlane_f64(wcur[d], __builtin_amdgcn_readfirstlane((int)c));
+#pragma unroll
+                            for (int j = 0; j < J; ++j)
+                                if (ok[j]) add_one(cur[d][j], lane + 64 * j, c, wc);
+                        }
+                    }
                 }
             }
         } else {
@@ -193,7 +246,11 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
                 s += (u64)(v > 0 ? v : 0);
             }
             total_of(dme_wave_sum_u64(s), w);
-            for (long long k = lane; k < K; k += 64) cell(row[k], k, w, nullptr);  // second read: L1 / L2
+            for (long long k = lane; k < K; k += 64) {  // second read: L1 / L2
+                const int v = row[k];
+                if (classify(v, k, nullptr))
+                    for (long long c = 0; c < C; ++c) add_one(v, k, c, w.p[c]);  // (weights from memory)
+            }
         }
     }
     bad_cells = dme_wave_sum_u64(bad_cells);
@@ -217,12 +274,12 @@ __global__ __launch_bounds__(WBLOCK) void stats_weighted_kernel(WArgs a) {
     }
     __syncthreads();
     // the workgroup's bins -> the global histograms (zero bins cost nothing)
-    const long long BK = (long long)B * K;
+    const long long BK = (long long)B * KP;
     for (long long i = tid; i < C * BK; i += WBLOCK) {
         const double x = h[i];
-        if (x != 0.0) {
+        if (x != 0.0) {  // (the padding columns k >= K stay zero)
             const long long c = i / BK, rem = i - c * BK;
-            const long long vb = rem / K, k = rem - vb * K;
+            const long long vb = rem / KP, k = rem - vb * KP;
             atomicAdd(&a.histW[(c * K + k) * a.nbins + vb + 1], x);
         }
     }
@@ -295,11 +352,14 @@ int stats_weighted(const int32_t* X, const double* weights, int64_t C, int64_t N
     if (TB * C * 8 > budget / 4) TB = budget / 4 / (C * 8);
     a.TB = (int)TB;
     budget -= TB * C * 8;
-    long long B = budget / (C * K * 8);
+    // (only the pitch matters: the base of the bins shifts every lane's bank alike)
+    const long long KP = (K + 31) & ~31LL;
+    a.KP = (int)KP;
+    long long B = budget / (C * KP * 8);
     if (B > nbins - 1) B = nbins - 1;
     if (B < 0) B = 0;
     a.B = (int)B;
-    const size_t lds = (size_t)(C * TB * 8 + C * B * K * 8 + (a.mxlds ? ((K * 4 + 7) & ~7LL) : 0));
+    const size_t lds = (size_t)(C * TB * 8 + C * B * KP * 8 + (a.mxlds ? ((K * 4 + 7) & ~7LL) : 0));
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
     // a workgroup should see enough rows to repay the flush of its bins
@@ -314,11 +374,25 @@ int stats_weighted(const int32_t* X, const double* weights, int64_t C, int64_t N
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WBLOCK), lds, (hipStream_t)stream, a);
         return DME_OK;
     };
+    auto by_c = [&](auto jtag) -> int {
+        constexpr int J = decltype(jtag)::value;
+        switch ((int)C) {
+            case 1: return launch(stats_weighted_kernel<J, 1>);
+            case 2: return launch(stats_weighted_kernel<J, 2>);
+            case 3: return launch(stats_weighted_kernel<J, 3>);
+            case 4: return launch(stats_weighted_kernel<J, 4>);
+            case 5: return launch(stats_weighted_kernel<J, 5>);
+            case 6: return launch(stats_weighted_kernel<J, 6>);
+            case 7: return launch(stats_weighted_kernel<J, 7>);
+            case 8: return launch(stats_weighted_kernel<J, 8>);
+            default: return launch(stats_weighted_kernel<J, 0>);
+        }
+    };
     int rc;
-    if (K <= 128) rc = launch(stats_weighted_kernel<2>);
-    else if (K <= 256) rc = launch(stats_weighted_kernel<4>);
-    else if (K <= 1024) rc = launch(stats_weighted_kernel<16>);
-    else rc = launch(stats_weighted_kernel<0>);
+    if (K <= 128) rc = by_c(std::integral_constant<int, 2>{});
+    else if (K <= 256) rc = by_c(std::integral_constant<int, 4>{});
+    else if (K <= 1024) rc = by_c(std::integral_constant<int, 16>{});
+    else rc = by_c(std::integral_constant<int, 0>{});
     if (rc) return rc;
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
