@@ -869,6 +869,21 @@ __global__ __launch_bounds__(64 * RED_SLICES) void hist_reduce_kernel(ReduceArgs
         const u32x4* src = (const u32x4*)(a.hist_part + idx4);
         const long long stride4 = a.part_words >> 2;
         long long g = threadIdx.y;
+        // sixteen loads in flight first: with one workgroup per CU (G = 256) that is a thread's whole
+        // share of the images in ONE round trip (four rounds of four before: the kernel is a chain of
+        // memory latencies, 14 us for 40 MB)
+        for (; g + 15 * RED_SLICES < a.G; g += 16 * RED_SLICES) {
+            u32x4 w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = src[(g + q * RED_SLICES) * stride4];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                lo[0] += w[q].x & 0xffffu; hi[0] += w[q].x >> 16;
+                lo[1] += w[q].y & 0xffffu; hi[1] += w[q].y >> 16;
+                lo[2] += w[q].z & 0xffffu; hi[2] += w[q].z >> 16;
+                lo[3] += w[q].w & 0xffffu; hi[3] += w[q].w >> 16;
+            }
+        }
         for (; g + 3 * RED_SLICES < a.G; g += 4 * RED_SLICES) {  // four loads in flight
             u32x4 w[4];
 #pragma unroll
