@@ -72,6 +72,8 @@ def main():
     line = {"workload": "heavy-tailed counts (BASELINE configs[4])", "K": K, "rows": N,
             "max_total": info["max_total"], "max_count": info["max_count"],
             "sum_lenU": int(lenU.sum()), "lenV": lenV,
+            "layout": "ragged" if uv.ragged is not None else "dense-padded",
+            "U_terms_allocated": int(uv.Uf.numel()), "dense_cells_K_x_max_count": K * info["max_count"],
             "stats_ms": float(np.mean(stats_ms)), "stats_GBps": b_stats / (np.mean(stats_ms) * 1e-3) / 1e9,
             "solve_ms": float(np.mean(solve_ms)), "iterations": out["n_iters"], "loss_evals": out["n_evals"],
             "launches": out["launches"], "exit": out["exit"],
