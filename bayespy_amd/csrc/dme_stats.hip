@@ -247,6 +247,14 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     __shared__ u64 sh_stat[8];
     __shared__ u64 sh_tot[2][TW > 1 ? W : 1][RB];  // teams: the waves' partial row totals
     __shared__ u32 sh_team[TW > 1 ? WR : 1];        // teams: parts published so far
+    // Packed int32 kernels (at their 128-register limit): the overflow store's address waits in LDS for
+    // the rare branch that needs it.  Read from the kernel argument there, it stayed live across the
+    // main loop (K = 8192: 1.85 -> 1.92 ms for 8 GB; from LDS 1.62 ms).  The uint16 kernels measured
+    // SLOWER that way (K = 16 384: 1.55 -> 1.71 ms) and read the argument.
+    __shared__ u64* sh_ovf;
+    if constexpr (PACK) {
+        if (tid == 0) sh_ovf = a.overflow;
+    }
     if (tid < 8) sh_stat[tid] = 0;
     if (tid < (TW > 1 ? WR : 1)) sh_team[tid] = 0;
     __syncthreads();
@@ -379,6 +387,27 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                 if (c >= dd) incl += up;
             }
             return (u32)__shfl((int)incl, lastLane);
+        }
+    };
+
+    // Cells with a count of nbins or more (rarer still than the rare global-atomic paths below) go to the
+    // overflow store from ONE copy of the store's code per site: the unrolled per-element code only
+    // marks them in a bit mask, and this loop - not unrolled, the value picked by a select chain -
+    // walks the marks.  (With the store's code inlined per element the rare branches grew the team
+    // kernels by a third and the widest rows lost 4-15 %.)  `half`: vals holds packed 16-bit pairs.
+    auto overflow_cells = [&](u32 ovm, auto& vals, long long k0, bool half, int kmod) {
+        u64* ovf = a.overflow;
+        if constexpr (PACK) ovf = *(u64* volatile*)&sh_ovf;
+#pragma nounroll
+        for (u32 m = ovm; m; m &= m - 1) {
+            const int e = __builtin_ctz(m);
+            const int t = half ? e >> 1 : e;
+            u32 v = 0;
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(vals) / sizeof(vals[0])); ++i) v = (t == i) ? vals[i] : v;
+            if (half) v = (e & 1) ? v >> 16 : v & 0xffffu;
+            const long long k = kmod ? (long long)(e % kmod) : k0 + e;
+            if (!dme_overflow_put(ovf, (u64)k, (u64)v, 1ULL)) atomicAdd(&sh_stat[1], 1ULL);
         }
     };
 
@@ -593,6 +622,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
 #pragma unroll
                         for (int e = 1; e < E; ++e) mr = max(mr, b.d[rb][j][e]);
                         if (__builtin_expect(mr > 0xFFFFu, 0)) {
+                            u32 ovm = 0;
 #pragma unroll
                             for (int e = 0; e < E; ++e) {
                                 const int v = (int)b.d[rb][j][e];
@@ -601,15 +631,21 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                     b.d[rb][j][e] = 0;
                                 } else if (v > 0xFFFF) {
                                     atomicMax(&sh_stat[4], (u64)v);
-                                    const long long k = (long long)opaque(chunk) * E + e;
-                                    if ((long long)v < nbins) {
-                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    } else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL)) {
-                                        atomicAdd(&sh_stat[1], 1ULL);
-                                    }
                                     acc[j][e] = mean_add(acc[j][e], (double)v, w);
-                                    b.d[rb][j][e] = 0;
+                                    if ((long long)v < nbins) {
+                                        const long long k = (long long)opaque(chunk) * E + e;
+                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                        b.d[rb][j][e] = 0;
+                                    } else {
+                                        ovm |= 1u << e;
+                                    }
                                 }
+                            }
+                            if (__builtin_expect(ovm != 0, 0)) {
+                                overflow_cells(ovm, b.d[rb][j], (long long)opaque(chunk) * E, false, 0);
+#pragma unroll
+                                for (int e = 0; e < E; ++e)
+                                    if ((ovm >> e) & 1u) b.d[rb][j][e] = 0;
                             }
                         }
 #pragma unroll
@@ -625,22 +661,33 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
 #pragma unroll
                     for (int q = 1; q < NDP; ++q) m = pk_max_u16(m, dwl[q]);
                     if (__builtin_expect(pk_min_u16(m, Bpk) != m, 0) && !DBG(4)) {
+                        u32 ovm = 0;
 #pragma unroll
                         for (int q = 0; q < NDP; ++q)
 #pragma unroll
                             for (int h = 0; h < (E >= 2 ? 2 : 1); ++h) {
                                 const u32 v = h ? (dwl[q] >> 16) : (dwl[q] & 0xffffu);
                                 if (v > (u32)B) {
-                                    const long long k = SUB > 1 ? (long long)((2 * q + h) % KC)
-                                                                : (long long)opaque(chunk) * E + 2 * q + h;
                                     atomicMax(&sh_stat[4], (u64)v);
-                                    if ((long long)v < nbins) atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                    else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL))
-                                        atomicAdd(&sh_stat[1], 1ULL);
                                     acc[j][2 * q + h] = mean_add(acc[j][2 * q + h], (double)v, wv[(2 * q + h) / KC % SUB]);
-                                    dwl[q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
+                                    if ((long long)v < nbins) {
+                                        const long long k = SUB > 1 ? (long long)((2 * q + h) % KC)
+                                                                    : (long long)opaque(chunk) * E + 2 * q + h;
+                                        atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                        dwl[q] &= h ? 0x0000ffffu : 0xffff0000u;  // done: clear it
+                                    } else {
+                                        ovm |= 1u << (2 * q + h);
+                                    }
                                 }
                             }
+                        if (__builtin_expect(ovm != 0, 0)) {
+                            overflow_cells(ovm, dwl, SUB > 1 ? 0LL : (long long)opaque(chunk) * E, true,
+                                           SUB > 1 ? KC : 0);
+#pragma unroll
+                            for (int q = 0; q < NDP; ++q)
+                                dwl[q] &= (((ovm >> (2 * q)) & 1u) ? 0xffff0000u : 0xffffffffu) &
+                                          (((ovm >> (2 * q + 1)) & 1u) ? 0x0000ffffu : 0xffffffffu);
+                        }
                     }
                     // one exec-masked region per DME_GROUP dwords: a lane enters it when any of its
                     // 2*DME_GROUP counts is non-zero; zero halves inside go to the sink row
@@ -695,6 +742,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
 #pragma unroll
                     for (int q = 1; q < ND; ++q) m = max(m, b.d[rb][j][q]);
                     if (__builtin_expect(m > (u32)B, 0) && !DBG(4)) {
+                        u32 ovm = 0;
 #pragma unroll
                         for (int e = 0; e < E; ++e) {
                             const int v = (int)b.d[rb][j][e];
@@ -703,15 +751,21 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                 b.d[rb][j][e] = 0;
                             } else if (v > B) {
                                 atomicMax(&sh_stat[4], (u64)v);
-                                const long long k = (long long)opaque(chunk) * E + e;
-                                if ((long long)v < nbins) {
-                                    atomicAdd(&a.hist[k * nbins + v], 1ULL);
-                                } else if (!dme_overflow_put(a.overflow, (u64)k, (u64)v, 1ULL)) {
-                                    atomicAdd(&sh_stat[1], 1ULL);
-                                }
                                 acc[j][e] = mean_add(acc[j][e], (double)v, w);
-                                b.d[rb][j][e] = 0;
+                                if ((long long)v < nbins) {
+                                    const long long k = (long long)opaque(chunk) * E + e;
+                                    atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                    b.d[rb][j][e] = 0;
+                                } else {
+                                    ovm |= 1u << e;
+                                }
                             }
+                        }
+                        if (__builtin_expect(ovm != 0, 0)) {
+                            overflow_cells(ovm, b.d[rb][j], (long long)opaque(chunk) * E, false, 0);
+#pragma unroll
+                            for (int e = 0; e < E; ++e)
+                                if ((ovm >> e) & 1u) b.d[rb][j][e] = 0;
                         }
                     }
                     // two counts share an LDS word; a zero count goes to the sink row
@@ -1322,7 +1376,11 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
                                   : useful(j, cl) * (j == 4 ? 0.95 : j == 5 ? 0.85 : 1.0);
             // (the packed int32 kernel of two vectors per lane runs 768 threads: K = 100 measured 4.45
             // TB/s with one vector per lane on 52 lanes against 3.67 with two on 63)
-            if (u > best * (pack ? 1.3 : 1.08)) {
+            // rows of 33 to 63 vectors fill one wave with J = 1: two of them side by side with two vectors
+            // per lane use the same share of the lanes and halve the per-row work of a wave (K = 400: 4.16
+            // -> 4.85 TB/s, K = 448: 4.63 -> 5.53, K = 480: 4.98 -> 5.68)
+            const bool pair_up = !pack && j == 2 && p.multi && p.J == 1 && p.R == 1 && u >= best;
+            if (u > best * (pack ? 1.3 : 1.08) || pair_up) {
                 best = u;
                 p.multi = true;
                 p.J = j;

@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--dense-message", action="store_true",
                     help="all-reduce K x nbins words instead of the occupied bins of every column")
     ap.add_argument("--lib", default=None, help="another build of libdme_hip.so to time (A/B comparisons)")
+    ap.add_argument("--free-first", action="store_true",
+                    help="drop the previous pass's DeviceStats (histograms, workspace) before the next one is made: "
+                         "every pass then gets the same blocks from torch's allocator instead of two sets in turn")
     args = ap.parse_args()
     if args.lib:
         from bayespy_amd import _lib
@@ -159,7 +162,10 @@ def main():
     for _ in range(args.warmup):
         one()
     ms = []
+    st = None
     for _ in range(args.steps):
+        if args.free_first:
+            st = None
         st, e0, e1 = one()
         torch.cuda.synchronize()
         ms.append(e0.elapsed_time(e1))
