@@ -314,9 +314,13 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             blob = git_blob_sha1(os.path.join(ROOT, "bayespy_amd", "csrc", "dme_stats.hip"))
+            blob_h = git_blob_sha1(os.path.join(ROOT, "bayespy_amd", "csrc", "dme_common.h"))
             if tj.get("dme_stats_hip_blob") != blob:
                 traffic_note = ("profiles/traffic.json was measured on dme_stats.hip blob %s, this tree "
                                 "holds %s" % (tj.get("dme_stats_hip_blob"), blob))
+            elif tj.get("dme_common_h_blob") != blob_h:  # the header the kernels include
+                traffic_note = ("profiles/traffic.json was measured on dme_common.h blob %s, this tree "
+                                "holds %s" % (tj.get("dme_common_h_blob"), blob_h))
             elif tj.get("N") != N or tj.get("K") != K:
                 traffic_note = "profiles/traffic.json is for N=%s K=%s" % (tj.get("N"), tj.get("K"))
             else:  # PMC traffic is per launch of the profiled shape only

@@ -17,9 +17,10 @@ step() {  # step NAME SECONDS cmd...: a GPU step under its own limit; a kill or 
   case $rc in 124|137|134|139) echo "stopping: $name was killed or crashed"; exit $rc;; esac
   return $rc
 }
+# the PMC traffic first: bench.py reads profiles/traffic.json (and reports null when it was measured on other sources)
+step traffic 600 bash benchmarks/pmc_bench_traffic.sh $COMMIT $OUT && cp $OUT/traffic.json profiles/traffic.json
 step bench 300 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 step kernel_trace 300 bash -c "cd /tmp && rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats -d /tmp/kt -o b -- python3 $ROOT/bench.py --no-cpu-baseline > /tmp/kt.json 2>/tmp/kt.err && python3 $ROOT/benchmarks/kstats.py /tmp/kt/b_results.db > $OUT/bench_kernel_stats.txt && cp /tmp/kt.json $OUT/bench_under_rocprof.json"
-step traffic 600 bash benchmarks/pmc_bench_traffic.sh $COMMIT $OUT
 for rows in 5000000 2500000 1250000; do
   step share_$rows 200 python3 bench.py --rows $rows --force-collective --no-cpu-baseline > $OUT/share_rows_$rows.json 2> $OUT/share_rows_$rows.err
 done

@@ -57,6 +57,7 @@ def main():
         "algorithmic_bytes_per_launch": float(N * K * (2 if dtype == "u16" else 4)),
         "N": N, "K": K,
         "dme_stats_hip_blob": blob(os.path.join(ROOT, "bayespy_amd", "csrc", "dme_stats.hip")),
+        "dme_common_h_blob": blob(os.path.join(ROOT, "bayespy_amd", "csrc", "dme_common.h")),
         "commit": commit,
     }
     print(json.dumps(out, indent=1))

@@ -102,6 +102,47 @@ def test_overflow_store_of_the_dense_passes(K, N, dense_bins, dtype, oracle):
     _lists_equal(a.finalize(), ref)
 
 
+@pytest.mark.parametrize("dtype,K", [("u16", 3000), ("u16", 9000), ("u16", 20_000), ("i32", 1000),
+                                     ("i32", 3000), ("i32", 6000), ("i32", 12_000)])
+def test_overflow_records_of_wide_rows(dtype, K):
+    """Rows that teams of waves share (and int32 rows of the packed kernels): cells planted beyond the
+    dense bins - below and, for int32, above 65535, several in one 8-column chunk of one row - come back
+    as exactly those records; the dense bins hold the rest.  No oracle: its dense U would be K x the
+    largest count."""
+    dev = _dev()
+    N, dense_bins = 1500, 8
+    rng = np.random.default_rng(K)
+    X = np.zeros((N, K), dtype=np.int64)
+    sel = rng.random((N, K)) < 6.0 / K
+    X[sel] = rng.integers(1, 12, size=int(sel.sum()))
+    big_hi = 60_000 if dtype == "u16" else 400_000
+    rows = rng.integers(0, N, size=60)
+    cols = rng.integers(0, K, size=60)
+    X[rows, cols] = rng.integers(dense_bins, big_hi, size=60)
+    base = (int(cols[0]) // 8) * 8  # three in a row's one chunk
+    X[rows[0], base:base + 3] = [big_hi - 1, dense_bins, big_hi - 2]
+    npdt = np.uint16 if dtype == "u16" else np.int32
+    Xd = torch.from_numpy(np.ascontiguousarray(X.astype(npdt))).cuda()
+    st = dev.DeviceStats(K, dense_bins=dense_bins, overflow_capacity=4096)
+    st.add_dense(Xd)
+    info = st.check()
+    assert info["rows"] == N and info["max_count"] == int(X.max())
+    ok, ov, on = st._overflow_records()
+    got = {}
+    for k, v, n in zip(ok.tolist(), ov.tolist(), on.tolist()):
+        got[(k, v)] = got.get((k, v), 0) + n
+    rr, cc = np.nonzero(X >= dense_bins)
+    want = {}
+    for k, v in zip(cc.tolist(), X[rr, cc].tolist()):
+        want[(k, v)] = want.get((k, v), 0) + 1
+    assert got == want
+    hist = st.hist.view(K, st.nbins).cpu().numpy()
+    for v in range(1, dense_bins):
+        assert np.array_equal(hist[:, v], (X == v).sum(axis=0)), v
+    w = 1.0 / (1.0 + X.sum(axis=1))
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), (X * w[:, None]).sum(axis=0), rtol=1e-12, atol=1e-300)
+
+
 def test_overflow_store_save_load_and_full_store(tmp_path, oracle):
     dev = _dev()
     rng = np.random.default_rng(5)
