@@ -198,14 +198,20 @@ struct StatsCfg {
 // SUB (with WIDE; K = 2 or 4 in rows that lie back to back): a 16-byte vector holds SUB whole rows,
 // a lane settles them by itself (row totals inside the lane).
 // TAIL: the rows end inside their last vector (a.tail elements of it belong to the row).
+// EARLY (PACK): a buffer's counts are packed to 16-bit pairs as soon as they have arrived and the buffer is
+// refilled at once, two steps ahead: two buffers of loads are in flight while the cells are counted, for
+// eight more registers.  What the widest rows and every shape that leaves lanes idle were short of
+// (int32 K = 16 384: 3.6 -> 5.8 TB/s, K = 10: 3.4 -> 4.4, K = 600: 3.8 -> 4.7); shapes that fill their waves
+// lose 4-7 % to it and run without (the plan decides).
 template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE = false, int SUB = 1,
-          bool TAIL = false>
+          bool TAIL = false, bool EARLY = false>
 __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK)) void stats_dense_kernel(StatsArgs a) {
     static_assert(TW == 1 || !MULTI, "teams are for long rows");
     static_assert(!WIDE || (MULTI && (sizeof(T) == 2 || PACK) && E == 8), "32-bit counters: side-by-side rows of 16-bit cells");
     static_assert(SUB == 1 || J == 1, "rows inside a vector: one vector per lane");
     static_assert(!TAIL || (E * sizeof(T) >= 16 && SUB == 1), "row ends inside full vectors only");
     static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
+    static_assert(!EARLY || PACK, "early refill: packed int32 kernels");
     constexpr int KC = E / SUB;  // columns of a row inside a vector (SUB > 1)
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
     constexpr bool IS16 = RAW16 || PACK;    // the cells are processed as packed 16-bit counts
@@ -411,7 +417,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
         }
     };
 
-    auto process_buf = [&](Buf& b, long long tile, int parity) {
+    auto process_buf = [&](Buf& b, long long tile, int parity, long long reload_tile) {
         // rows that end inside a vector: clear what the last vector of a row holds beyond the row
         if constexpr (TAIL) {
             // what the last vector of a row keeps (a.tail elements)
@@ -437,6 +443,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
         // ---- row totals of all RB row groups first (independent DPP chains interleave) ----------
         SumT tot[RB];
         u32 tsub[RB][SUB];  // SUB > 1: the totals of the rows inside the lane's vector
+        u32 mraw = 0;       // int32: the lane's largest raw count over the buffer (negatives read huge)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             if constexpr (SUB > 1) {
@@ -473,6 +480,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                         m = max(m, b.d[rb][j][q]);
                         s32 += b.d[rb][j][q];
                     }
+                mraw = max(mraw, m);
                 if (__builtin_expect(!__any(m >= (1u << 20)), 1)) {
                     if constexpr (MULTI) {
                         tot[rb] = (SumT)multi_total(s32);
@@ -502,6 +510,30 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                     }
                 }
             }
+        }
+        // counts packed to 16-bit pairs; those that do not fit (>= 65536, or negative) are marked, packed
+        // as zeros, and read again from memory when their turn comes
+        u32 P[EARLY ? RB : 1][EARLY ? J : 1][4];
+        u32 rmask[EARLY ? RB : 1][EARLY ? J : 1];
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    u32 rm = 0;
+                    if (__builtin_expect(mraw > 0xFFFFu, 0)) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e)
+                            if (b.d[rb][j][e] > 0xFFFFu) {
+                                rm |= 1u << e;
+                                b.d[rb][j][e] = 0;
+                            }
+                    }
+                    rmask[rb][j] = rm;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) P[rb][j][q] = b.d[rb][j][2 * q] | (b.d[rb][j][2 * q + 1] << 16);
+                }
+            load_buf(b, reload_tile);
         }
         if constexpr (TW > 1) {
             // The team's waves add their parts.  No workgroup barrier: that would march all the
@@ -618,9 +650,37 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                     if constexpr (PACK) {
                         // counts >= 65536 and negatives (huge as unsigned) are settled here and
                         // cleared; what is left fits 16 bits
-                        u32 mr = b.d[rb][j][0];
+                        u32 mr = 0;
+                        if constexpr (EARLY) {
+                            const u32 rm = rmask[rb][j];
+                            if (__builtin_expect(rm != 0, 0)) {
+                                const long long rowi = row0 + pg * R + r;
+#pragma nounroll
+                                for (u32 mm = rm; mm; mm &= mm - 1) {
+                                    const int e = __builtin_ctz(mm);
+                                    const long long k = (long long)opaque(chunk) * E + e;
+                                    const int v = (int)Xp[rowi * a.ld + k];
+                                    if (v < 0) {
+                                        atomicAdd(&sh_stat[3], 1ULL);
+                                    } else {
+                                        atomicMax(&sh_stat[4], (u64)v);
+                                        if ((long long)v < nbins) {
+                                            atomicAdd(&a.hist[k * nbins + v], 1ULL);
+                                        } else {
+                                            u64* ovf = *(u64* volatile*)&sh_ovf;
+                                            if (!dme_overflow_put(ovf, (u64)k, (u64)v, 1ULL)) atomicAdd(&sh_stat[1], 1ULL);
+                                        }
 #pragma unroll
-                        for (int e = 1; e < E; ++e) mr = max(mr, b.d[rb][j][e]);
+                                        for (int t = 0; t < E; ++t)
+                                            acc[j][t] = (t == e) ? mean_add(acc[j][t], (double)v, w) : acc[j][t];
+                                    }
+                                }
+                            }
+                        } else {
+                            mr = b.d[rb][j][0];
+#pragma unroll
+                            for (int e = 1; e < E; ++e) mr = max(mr, b.d[rb][j][e]);
+                        }
                         if (__builtin_expect(mr > 0xFFFFu, 0)) {
                             u32 ovm = 0;
 #pragma unroll
@@ -648,9 +708,14 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                                     if ((ovm >> e) & 1u) b.d[rb][j][e] = 0;
                             }
                         }
+                        if constexpr (EARLY) {
 #pragma unroll
-                        for (int q = 0; q < NDP; ++q)
-                            dwl[q] = b.d[rb][j][2 * q] | (b.d[rb][j][2 * q + 1] << 16);
+                            for (int q = 0; q < NDP; ++q) dwl[q] = P[EARLY ? rb : 0][EARLY ? j : 0][q];
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < NDP; ++q)
+                                dwl[q] = b.d[rb][j][2 * q] | (b.d[rb][j][2 * q + 1] << 16);
+                        }
                     } else {
 #pragma unroll
                         for (int q = 0; q < NDP; ++q) dwl[q] = b.d[rb][j][q];
@@ -799,13 +864,25 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
             long long tile = tile0;
             long long k = 0;
             load_buf(bufA, tile);
+            if constexpr (EARLY) {
+                // the buffers refill themselves inside process_buf, two steps ahead
+                load_buf(bufB, tile + tile_pitch);
+                while (true) {
+                    process_buf(bufA, tile, 0, tile + 2 * tile_pitch);
+                    tile += tile_pitch;
+                    if (++k >= nsteps) break;
+                    process_buf(bufB, tile, 1, tile + 2 * tile_pitch);
+                    tile += tile_pitch;
+                    if (++k >= nsteps) break;
+                }
+            } else
             while (true) {
                 load_buf(bufB, tile + tile_pitch);
-                process_buf(bufA, tile, 0);
+                process_buf(bufA, tile, 0, 0);
                 tile += tile_pitch;
                 if (++k >= nsteps) break;
                 load_buf(bufA, tile + tile_pitch);
-                process_buf(bufB, tile, 1);
+                process_buf(bufB, tile, 1, 0);
                 tile += tile_pitch;
                 if (++k >= nsteps) break;
             }
@@ -1289,6 +1366,7 @@ struct Plan {
     bool multi;
     bool pack;  // int32 rows through the packed kernel (E = 8 columns per chunk)
     bool wide;  // 32-bit LDS counters (side-by-side uint16 rows, very many of them)
+    bool early; // packed int32: buffers refilled as soon as their counts are packed (see the kernel)
     int sub;    // rows inside a 16-byte vector (K = 2 or 4, rows back to back), else 1
 };
 
@@ -1415,6 +1493,16 @@ int plan_dense(int elem_bytes, const void* X, long long N, long long K, long lon
         p.J = (int)jtot;
         p.R = 1;
     }
+    // Packed int32 rows: two buffers of loads in flight wherever one leaves the memory pipe short - teams of
+    // four waves or more (the widest rows: 3.6 -> 5.8 TB/s at K = 16 384), rows that end inside a vector
+    // (K = 10: 3.4 -> 4.4, K = 1001: 4.1 -> 4.9) and shapes that leave a tenth or more of the lane slots
+    // empty (K = 600: 3.8 -> 4.7, K = 1536: 4.4 -> 5.1).  Shapes that fill their waves measured 4-7 %
+    // slower with it (K = 8, 16, 512, 1000, 1024) and run without.
+    if (pack) {
+        const double slots = p.multi ? 64.0 * p.J : 64.0 * p.J * p.TW;
+        const double fill = (double)(C * (p.multi ? p.R : 1)) / slots;
+        p.early = p.TW >= 4 || p.tail != 0 || fill < 0.9;
+    }
     int PW = E >= 2 ? E / 2 : 1;
     int cus = dme_device_cus();
     if (cus <= 0) cus = 256;
@@ -1515,9 +1603,22 @@ int launch_dense(const StatsArgs& a, const Plan& p, hipStream_t s) {
     return launch_dense_t<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, false>(a, p, s);
 }
 
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE, int SUB, bool TAIL,
+          bool EARLY>
+int launch_dense_e(const StatsArgs& a, const Plan& p, hipStream_t s);
+
 template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE, int SUB, bool TAIL>
 int launch_dense_t(const StatsArgs& a, const Plan& p, hipStream_t s) {
-    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL>;
+    if constexpr (PACK) {
+        if (p.early) return launch_dense_e<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, true>(a, p, s);
+    }
+    return launch_dense_e<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, false>(a, p, s);
+}
+
+template <typename T, int E, int J, bool MULTI, bool PACK, int TW, bool SCAN, bool WIDE, int SUB, bool TAIL,
+          bool EARLY>
+int launch_dense_e(const StatsArgs& a, const Plan& p, hipStream_t s) {
+    auto kern = stats_dense_kernel<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, EARLY>;
     // allow the full 160 KiB of dynamic LDS (the default cap is 64 KiB); once per kernel and device
     static std::atomic<bool> attr_set[64];  // zero-initialised; racing first calls both set the attribute
     int dev = 0;

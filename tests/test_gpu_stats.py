@@ -589,9 +589,10 @@ def test_packed_int32_kernel_exceptions(oracle):
     of 65536 and more are settled one by one and must land in the same bins; negatives are reported."""
     dev = _dev()
     rng = np.random.default_rng(42)
-    for K in (512, 1000, 2048, 4096):
+    # (10, 100, 600, 1001, 3000, 4096: the kernels that refill their buffers early and read such cells again)
+    for K in (512, 1000, 2048, 4096, 10, 100, 600, 1001, 3000):
         N = 300
-        X = rng.integers(1, 40, size=(N, K)) * (rng.random((N, K)) < 0.05)
+        X = rng.integers(1, 40, size=(N, K)) * (rng.random((N, K)) < max(0.05, 2.0 / K))
         for v in (65535, 65536, 70000, 200000, 65537):
             X[rng.integers(0, N), rng.integers(0, K)] = v
         ref = oracle.append_rows(X.astype(np.int32))
@@ -600,7 +601,7 @@ def test_packed_int32_kernel_exceptions(oracle):
         _assert_uv_equal(uv, ref)
         np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-12, atol=1e-300)
         Xn = X.copy()
-        Xn[5, 17] = -3
+        Xn[5, 17 % K] = -3
         bad = dev.DeviceStats(K)
         bad.add_dense(_to_dev(Xn, "i32"), max_count=200000, max_total=int(X.sum(axis=1).max()))
         with pytest.raises(ValueError, match="negative"):
