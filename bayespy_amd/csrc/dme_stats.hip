@@ -211,7 +211,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
     static_assert(SUB == 1 || J == 1, "rows inside a vector: one vector per lane");
     static_assert(!TAIL || (E * sizeof(T) >= 16 && SUB == 1), "row ends inside full vectors only");
     static_assert(SUB == 1 || (WIDE && !SCAN && (SUB == 2 || SUB == 4)), "rows inside a vector need WIDE");
-    static_assert(!EARLY || PACK, "early refill: packed int32 kernels");
+    static_assert(!EARLY || PACK || sizeof(T) == 2, "early refill: kernels that count 16-bit pairs");
     constexpr int KC = E / SUB;  // columns of a row inside a vector (SUB > 1)
     constexpr bool RAW16 = sizeof(T) == 2;  // the buffers hold packed 16-bit counts
     constexpr bool IS16 = RAW16 || PACK;    // the cells are processed as packed 16-bit counts
@@ -513,9 +513,19 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
         }
         // counts packed to 16-bit pairs; those that do not fit (>= 65536, or negative) are marked, packed
         // as zeros, and read again from memory when their turn comes
-        u32 P[EARLY ? RB : 1][EARLY ? J : 1][4];
+        u32 P[EARLY ? RB : 1][EARLY ? J : 1][NDP];
         u32 rmask[EARLY ? RB : 1][EARLY ? J : 1];
-        if constexpr (EARLY) {
+        if constexpr (EARLY && !PACK) {
+            // uint16 rows are 16-bit pairs as they stand: the copy costs registers, no instructions
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int q = 0; q < NDP; ++q) P[rb][j][q] = b.d[rb][j][q];
+            load_buf(b, reload_tile);
+        }
+        if constexpr (EARLY && PACK) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -718,7 +728,7 @@ __global__ __launch_bounds__((StatsCfg<J, E, (int)sizeof(T), TW, MULTI>::BLOCK))
                         }
                     } else {
 #pragma unroll
-                        for (int q = 0; q < NDP; ++q) dwl[q] = b.d[rb][j][q];
+                        for (int q = 0; q < NDP; ++q) dwl[q] = EARLY ? P[EARLY ? rb : 0][EARLY ? j : 0][q] : b.d[rb][j][q];
                     }
                     // rare path first: any count > B in this vector?  packed 16-bit max over the
                     // vector, then min(m, B|B) != m  <=>  some half exceeds B
@@ -1612,6 +1622,9 @@ int launch_dense_t(const StatsArgs& a, const Plan& p, hipStream_t s) {
     if constexpr (PACK) {
         if (p.early) return launch_dense_e<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, true>(a, p, s);
     }
+#ifdef DME_U16_EARLY_ALL  // experiment: every uint16 kernel with three buffers
+    if constexpr (sizeof(T) == 2) return launch_dense_e<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, true>(a, p, s);
+#endif
     return launch_dense_e<T, E, J, MULTI, PACK, TW, SCAN, WIDE, SUB, TAIL, false>(a, p, s);
 }
 
