@@ -835,6 +835,7 @@ class WeightedStats:
         if not 1 <= self.C <= 64:
             raise ValueError("C must be in 1..64")
         self.nbins, self.tbins = 2, 2
+        self._ws = None  # workspace of the statistics pass, kept between calls
         self._alloc()
 
     def _alloc(self):
@@ -868,10 +869,17 @@ class WeightedStats:
         weights = weights.contiguous()
         self.reserve(max_count, max_total)
         with _on(self.device):
-            _lib.check(_lib.lib().dme_stats_dense_weighted_batch_i32(
+            L = _lib.lib()
+            # the workgroups' images of their bins (added up by a second kernel); small inputs need none
+            need = int(L.dme_stats_weighted_workspace_bytes(self.K, self.C, self.nbins, self.tbins))
+            if X.shape[0] < 8192:
+                need = 0
+            if need and (self._ws is None or self._ws.numel() < need):
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(L.dme_stats_dense_weighted_batch_ws_i32(
                 X.data_ptr(), _ptr(weights), self.C, X.shape[0], self.K, X.stride(0),
                 _ptr(self.histW), self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol),
-                _ptr(self.maxtot), _ptr(self.status), _stream()))
+                _ptr(self.maxtot), _ptr(self.status), _ptr(self._ws) if need else None, need, _stream()))
 
     def check(self):
         st = self.status.cpu().numpy()

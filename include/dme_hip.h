@@ -244,6 +244,21 @@ int dme_stats_dense_weighted_batch_i32(const int32_t* X /*[dev]*/,
                                        int64_t nbins, double* histVW /*[dev]*/, int64_t tbins,
                                        int64_t* maxcol /*[dev][K]*/, int64_t* maxtot /*[dev][1]*/,
                                        uint64_t* status /*[dev]*/, void* stream);
+/* The same pass with a workspace (dme_stats_weighted_workspace_bytes(K, C, nbins, tbins) bytes, 8-byte
+ * aligned device memory, contents irrelevant before and after): every workgroup then leaves its bins as
+ * one image and a second kernel adds the images in a fixed order, instead of 256 workgroups sending their
+ * non-zero bins to the same few thousand addresses with fp64 atomics (1 M rows x 100 columns x 5 weights:
+ * 0.37 -> see profiles/r3_weighted_em.json).  Same reference lines as above (DE/dme.py:119,123 with weight
+ * != 1; CPT/dirichletMixtureEstimation.py:129-133).  workspace NULL, or smaller than asked for: the pass
+ * of dme_stats_dense_weighted_batch_i32. */
+int64_t dme_stats_weighted_workspace_bytes(int64_t K, int64_t C, int64_t nbins, int64_t tbins);
+int dme_stats_dense_weighted_batch_ws_i32(const int32_t* X /*[dev]*/,
+                                          const double* weights /*[dev][N][C]*/, int64_t C, int64_t N,
+                                          int64_t K, int64_t ld, double* histW /*[dev]*/,
+                                          int64_t nbins, double* histVW /*[dev]*/, int64_t tbins,
+                                          int64_t* maxcol /*[dev][K]*/, int64_t* maxtot /*[dev][1]*/,
+                                          uint64_t* status /*[dev]*/, void* workspace /*[dev]*/,
+                                          int64_t workspace_bytes, void* stream);
 int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t nbins, const double* histVW,
                              int64_t tbins, const int64_t* maxcol, const int64_t* maxtot,
                              double* Uf /*[dev]*/, int64_t ldU, int64_t* lenU /*[dev]*/,

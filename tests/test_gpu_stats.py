@@ -638,6 +638,44 @@ def test_csr_partitioned_fuzz_vs_oracle(oracle, seed):
     np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
 
 
+@pytest.mark.parametrize("K,huge", [(50_000, False), (50_000, True), (65_536, False), (5000, False)])
+def test_csr_rows_longer_than_a_tile_vs_oracle(oracle, K, huge):
+    """Rows of 4097 ... 20 000 stored entries through the tile partition kernel (4096 entries per tile,
+    a workgroup's range ~ a few tiles): a row that fills a tile exactly, rows that span two, three and
+    five tiles and two workgroups' ranges, the first and the last row of the matrix among them, long rows
+    back to back, empty rows around them; `huge` plants a count of 2^19 in a long row (64-bit row
+    totals).  Row totals of the longest rows exceed what a record holds (16 383): their entries take the
+    rare path.  DE/dme.py:113-123 against the oracle, cell by cell."""
+    dev = _dev()
+    rng = np.random.default_rng(4242 + K + int(huge))
+    N = 3000
+    lens = rng.poisson(12, size=N)
+    lens[rng.random(N) < 0.1] = 0
+    for j, l in [(0, 4500), (100, 4096), (101, 4097), (102, 4095), (700, 9000), (701, 0), (702, 8200),
+                 (1500, 20_000), (2200, 12_288), (2201, 5000), (N - 1, 6000)]:
+        lens[j] = min(l, K)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    col = np.concatenate([rng.choice(K, size=l, replace=False) if l else np.zeros(0, dtype=np.int64)
+                          for l in lens]).astype(np.int32)
+    val = rng.geometric(0.6, size=col.size).astype(np.int32)
+    val[rng.random(col.size) < 0.02] = 0
+    val[rng.random(col.size) < 0.002] = 300            # beyond a record's 8-bit count
+    if huge:
+        val[rowptr[700] + 5000] = 1 << 19
+        val[rowptr[20] : rowptr[21]] = 1               # a short row in the same run of tiles stays exact
+    st = dev.DeviceStats(K)
+    st.add_csr(torch.from_numpy(rowptr).cuda(), torch.from_numpy(col).cuda(), torch.from_numpy(val).cuda())
+    info = st.check()
+    assert info["rows"] == N
+    totals = np.add.reduceat(np.append(val, 0).astype(np.int64), rowptr[:-1])
+    totals[lens == 0] = 0
+    assert info["max_total"] == int(totals.max())
+    assert K < 20_000 or info["max_total"] >= (1 << 14)  # (K = 5000 caps the rows at 5000 entries)
+    ref = oracle.append_rows_csr(rowptr, col, val, K)
+    _assert_uv_equal(st.finalize(), ref)
+    np.testing.assert_allclose(st.init_acc.cpu().numpy(), ref.init_acc, rtol=1e-11, atol=1e-300)
+
+
 @pytest.mark.parametrize("K,N,max_total", [(512, 16_000_000, 300), (8, 40_000_000, 40),
                                            (24, 5_000_000, 50), (2, 6_000_000, 60)])
 def test_more_rows_than_one_round_of_workgroups(K, N, max_total):

@@ -89,3 +89,42 @@ def test_weighted_bounds_and_negatives_are_reported():
         ws.check()
     with pytest.raises(ValueError):
         device.WeightedStats(3, C=2).add_dense(X, w, 9, 13)  # one weight per row, two expected
+
+
+@pytest.mark.parametrize("N,K,C,vmax,density", [(40_000, 100, 5, 60, 0.3), (20_000, 300, 2, 12, 0.2),
+                                                (10_000, 1500, 1, 4, 0.05), (9000, 64, 8, 200, 0.5)])
+def test_weighted_images_path_vs_oracle_and_atomics_path(oracle, N, K, C, vmax, density):
+    """From 32 workgroups on (8192 rows) and with a workspace the workgroups leave their LDS bins as images
+    and weighted_reduce_kernel adds them up (dme_stats_dense_weighted_batch_ws_i32); without a workspace they
+    send them to the global histograms with atomics.  Both against the oracle's loops (DE/dme.py:113-123
+    with weights), on top of statistics that are already there (two calls), and against each other."""
+    from bayespy_amd import device, _lib
+    rng = np.random.default_rng(N + K + C)
+    X = _rows(rng, N, K, vmax, density)
+    X[5, 3] = vmax + 40   # beyond what most rows hold: the global-atomics path beside the images
+    R = rng.dirichlet(np.ones(C), size=N) if C > 1 else rng.random((N, 1))
+    mc, mt = int(X.max()), int(X.sum(axis=1).max())
+    Xd, Rd = torch.from_numpy(X).cuda(), torch.from_numpy(np.ascontiguousarray(R)).cuda()
+    ws = device.WeightedStats(K, C=C)
+    half = N // 2 + 37
+    ws.add_dense(Xd[:half], Rd[:half], mc, mt)     # N // 2 + 37 >= 4500 rows ... images only from 8192 on
+    ws.add_dense(Xd, Rd, mc, mt)                   # the whole matrix on top: every row counted twice more
+    ws.check()
+    assert ws._ws is not None and int(ws.status[0]) == N + half
+    # the same through the raw entry without a workspace
+    L = _lib.lib()
+    ref = device.WeightedStats(K, C=C)
+    ref.reserve(mc, mt)
+    for lo, hi in ((0, half), (0, N)):
+        _lib.check(L.dme_stats_dense_weighted_batch_i32(
+            Xd[lo:hi].data_ptr(), Rd[lo:hi].data_ptr(), C, hi - lo, K, Xd.stride(0), ref.histW.data_ptr(),
+            ref.nbins, ref.histVW.data_ptr(), ref.tbins, ref.maxcol.data_ptr(), ref.maxtot.data_ptr(),
+            ref.status.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ws.histW.cpu().numpy(), ref.histW.cpu().numpy(), rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(ws.histVW.cpu().numpy(), ref.histVW.cpu().numpy(), rtol=1e-12, atol=1e-300)
+    assert torch.equal(ws.maxcol, ref.maxcol) and torch.equal(ws.maxtot, ref.maxtot)
+    X2 = np.concatenate([X[:half], X])
+    for c in range(C):
+        _compare(ws.to_uv(c), oracle.append_rows_weighted(X2, np.concatenate([R[:half, c], R[:, c]])))
+    # bit-reproducible for the same images? no: LDS atomics inside a workgroup add in arrival order.
