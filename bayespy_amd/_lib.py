@@ -57,6 +57,8 @@ SIGNATURES = {
     "dme_stats_dense_weighted_batch_ws_i32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp,
                                                      _vp, _vp, _vp, _i64, _vp]),
     "dme_suffix_scan_weighted": (_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "dme_suffix_scan_weighted_batch": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64,
+                                              _vp, _vp]),
     "dme_cli_init_alphas": (_int, [_vp, _i64, _vp, _vp]),
     "dme_shard_message_words": (_i64, [_i64, _i64, _i64, _i64]),
     "dme_shard_pack": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),

@@ -365,7 +365,18 @@ __global__ __launch_bounds__(RBLOCK) void weighted_reduce_kernel(WArgs a, int ni
 __global__ __launch_bounds__(256) void suffix_scan_weighted_kernel(
     const double* histW, long long K, long long nbins, const double* histVW, long long tbins,
     const long long* maxcol, const long long* maxtot, double* Uf, long long ldU, long long* lenU,
-    double* Vf, long long capV, long long* lenV) {
+    double* Vf, long long capV, long long* lenV, long long sU, long long sLen) {
+    // blockIdx.y = weight column c (dme_suffix_scan_weighted_batch): its histograms lie K * nbins / tbins
+    // doubles further on, its U / V / lengths sU / capV / sLen / 1 elements
+    {
+        const long long c = blockIdx.y;
+        histW += c * K * nbins;
+        histVW += c * tbins;
+        Uf += c * sU;
+        lenU += c * sLen;
+        Vf += c * capV;
+        lenV += c;
+    }
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > K) return;
     const bool isV = k == K;
@@ -534,7 +545,24 @@ extern "C" int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t 
     hipLaunchKernelGGL(suffix_scan_weighted_kernel, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256),
                        0, (hipStream_t)stream, histW, (long long)K, (long long)nbins, histVW,
                        (long long)tbins, (const long long*)maxcol, (const long long*)maxtot, Uf,
-                       (long long)ldU, (long long*)lenU, Vf, (long long)capV, (long long*)lenV);
+                       (long long)ldU, (long long*)lenU, Vf, (long long)capV, (long long*)lenV, 0LL, 0LL);
+    DME_HIP_CHECK(hipGetLastError());
+    return DME_OK;
+}
+
+extern "C" int dme_suffix_scan_weighted_batch(const double* histW, int64_t C, int64_t K, int64_t nbins,
+                                              const double* histVW, int64_t tbins, const int64_t* maxcol,
+                                              const int64_t* maxtot, double* Uf, int64_t ldU,
+                                              int64_t* lenU, double* Vf, int64_t capV, int64_t* lenV,
+                                              void* stream) {
+    DME_REQUIRE(C >= 1 && C <= 64 && K >= 1 && nbins >= 1 && tbins >= 1, "bad shape");
+    DME_REQUIRE(ldU >= nbins - 1 && capV >= tbins - 1, "U/V too short for the histograms");
+    DME_REQUIRE(histW && histVW && maxcol && maxtot && Uf && lenU && Vf && lenV, "null pointer");
+    hipLaunchKernelGGL(suffix_scan_weighted_kernel, dim3((unsigned)((K + 1 + 255) / 256), (unsigned)C),
+                       dim3(256), 0, (hipStream_t)stream, histW, (long long)K, (long long)nbins, histVW,
+                       (long long)tbins, (const long long*)maxcol, (const long long*)maxtot, Uf,
+                       (long long)ldU, (long long*)lenU, Vf, (long long)capV, (long long*)lenV,
+                       (long long)(K * ldU), (long long)K);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }

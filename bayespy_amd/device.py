@@ -915,6 +915,27 @@ class WeightedStats:
         uv = DeviceUV(self.K, buf[:self.K * ldU], ldU, lens[:self.K], buf[self.K * ldU:], lens[self.K:])
         return self.add_into(uv, c)
 
+    def to_uvs(self):
+        """The statistics of all C weight columns as C DeviceUVs from ONE launch and two allocations
+        (dme_suffix_scan_weighted_batch): what an E-step hands to the C solves of the M-step."""
+        C, K = self.C, self.K
+        ldU, capV = max(self.nbins - 1, 1), max(self.tbins - 1, 1)
+        with _on(self.device):
+            buf = torch.zeros(C * (K * ldU + capV), dtype=torch.float64, device=self.device)
+            lens = torch.zeros(C * (K + 1), dtype=torch.int64, device=self.device)
+            Uf, Vf = buf[:C * K * ldU], buf[C * K * ldU:]
+            lenU, lenV = lens[:C * K], lens[C * K:]
+            _lib.check(_lib.lib().dme_suffix_scan_weighted_batch(
+                _ptr(self.histW), C, K, self.nbins, _ptr(self.histVW), self.tbins, _ptr(self.maxcol),
+                _ptr(self.maxtot), _ptr(Uf), ldU, _ptr(lenU), _ptr(Vf), capV, _ptr(lenV), _stream()))
+        uvs = []
+        for c in range(C):
+            uv = DeviceUV(K, Uf[c * K * ldU:(c + 1) * K * ldU], ldU, lenU[c * K:(c + 1) * K],
+                          Vf[c * capV:(c + 1) * capV], lenV[c:c + 1])
+            uv.Ui = uv.Vi = None
+            uvs.append(uv)
+        return uvs
+
 
 def predicted_step(hconst, hdiag, grad, alphas=None, device=None):
     """getPredictedStep (alphas None) / getPredictedStepAlt on the device (DE/dme.py:67-80)."""

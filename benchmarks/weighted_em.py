@@ -44,7 +44,7 @@ def main():
         e0.record()
         ws.add_dense(X, R, M, M)
         e1.record()
-        uvs = [ws.to_uv(c) for c in range(C)]
+        uvs = ws.to_uvs()
         e2.record()
         torch.cuda.synchronize()
         if it >= 2:

@@ -265,6 +265,16 @@ int dme_suffix_scan_weighted(const double* histW, int64_t K, int64_t nbins, cons
                              double* Vf /*[dev]*/, int64_t capV, int64_t* lenV /*[dev]*/,
                              void* stream);
 
+/* dme_suffix_scan_weighted for all C weight columns of a batch in one launch (the C component statistics
+ * an E-step of CPT/dirichletMixtureEstimation.py:128-133 hands to C solves): histW [C][K][nbins], histVW
+ * [C][tbins] as dme_stats_dense_weighted_batch_i32 fills them; Uf [C][K][ldU], lenU [C][K], Vf [C][capV],
+ * lenV [C]. */
+int dme_suffix_scan_weighted_batch(const double* histW, int64_t C, int64_t K, int64_t nbins,
+                                   const double* histVW, int64_t tbins, const int64_t* maxcol,
+                                   const int64_t* maxtot, double* Uf /*[dev]*/, int64_t ldU,
+                                   int64_t* lenU /*[dev]*/, double* Vf /*[dev]*/, int64_t capV,
+                                   int64_t* lenV /*[dev]*/, void* stream);
+
 /* DE/fdp.py:104-108: alpha0[k] = init_acc[k] / (sum(init_acc) + 0.01) + 0.01 */
 int dme_cli_init_alphas(const double* init_acc /*[dev]*/, int64_t K, double* alpha0 /*[dev]*/,
                         void* stream);

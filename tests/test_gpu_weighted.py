@@ -125,6 +125,10 @@ def test_weighted_images_path_vs_oracle_and_atomics_path(oracle, N, K, C, vmax, 
     np.testing.assert_allclose(ws.histVW.cpu().numpy(), ref.histVW.cpu().numpy(), rtol=1e-12, atol=1e-300)
     assert torch.equal(ws.maxcol, ref.maxcol) and torch.equal(ws.maxtot, ref.maxtot)
     X2 = np.concatenate([X[:half], X])
+    uvs = ws.to_uvs()   # all C components from one launch: the same bits as one launch per component
     for c in range(C):
-        _compare(ws.to_uv(c), oracle.append_rows_weighted(X2, np.concatenate([R[:half, c], R[:, c]])))
+        one = ws.to_uv(c)
+        _compare(one, oracle.append_rows_weighted(X2, np.concatenate([R[:half, c], R[:, c]])))
+        assert torch.equal(uvs[c].Uf, one.Uf) and torch.equal(uvs[c].Vf, one.Vf)
+        assert torch.equal(uvs[c].lenU, one.lenU) and torch.equal(uvs[c].lenV, one.lenV)
     # bit-reproducible for the same images? no: LDS atomics inside a workgroup add in arrival order.
