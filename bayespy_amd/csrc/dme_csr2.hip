@@ -1354,8 +1354,16 @@ __global__ __launch_bounds__(BBLOCK) void csr2_bucket_kernel(BucketArgs a) {
 }
 
 // hist[k][1..BL] += the counters of every run of bucket b; init_acc[k] += its accumulators.
-// grid (NB, ceil(CB*BL / 1024)).
+// grid (NB, ceil(CB / RCT)): a block takes RCT = 32 columns of the bucket and all their bins.  The images
+// are bin-major (a bin's columns side by side), hist is column-major (a column's bins side by side): the
+// sums of 32 bins x 32 columns cross over through LDS, so that the images are read in 128-byte pieces and
+// hist is updated in 256-byte pieces (with a thread per image cell, consecutive threads updated hist
+// 8 bytes at a time at a stride of nbins * 8 bytes - 1.25 M scattered read-modify-writes for the shard of
+// BASELINE configs[3]: 82 us).
+constexpr int RCT = 32;
 __global__ __launch_bounds__(BBLOCK) void csr2_reduce_kernel(BucketArgs a) {
+    static_assert(BBLOCK == 32 * RCT, "a block is 32 bins x RCT columns");
+    __shared__ u64 tile[32][RCT + 1];
     const int b = blockIdx.x, tid = threadIdx.x;
     const u32 s0 = a.bstart[b], s1 = a.bstart[b + 1];
     if (s1 == s0) return;
@@ -1364,22 +1372,32 @@ __global__ __launch_bounds__(BBLOCK) void csr2_reduce_kernel(BucketArgs a) {
     const int w_lo = (int)(s0 / piece), w_hi = (int)((s1 - 1) / piece);
     const long long kbase = (long long)b << a.sh;
     const int cells = CB * a.BL;
-    const int i = blockIdx.y * BBLOCK + tid;
-    if (i < cells) {
-        u64 sum = 0;
-        const char* img = a.images + 8LL * a.AC * CB + 4LL * i;
-        int w = w_lo;
-        for (; w + 7 <= w_hi; w += 8) {
-            u32 x[8];
+    {
+        const int c0 = (int)blockIdx.y * RCT;            // first column (inside the bucket) of this block
+        const int ct = CB - c0 < RCT ? CB - c0 : RCT;    // (< RCT only for buckets of fewer than RCT columns)
+        const int lc = tid & (RCT - 1), lb = tid / RCT;  // reading: column lc of bin lb of a group of 32 bins
+        const int wc = tid >> 5, wb = tid & 31;          // writing: bin wb of column wc
+        for (int bin0 = 0; bin0 < a.BL; bin0 += 32) {
+            const int bin = bin0 + lb;                   // 0-based: counts of bin + 1
+            u64 sum = 0;
+            if (bin < a.BL && lc < ct) {
+                const char* img = a.images + 8LL * a.AC * CB + 4LL * ((long long)bin * CB + c0 + lc);
+                int w = w_lo;
+                for (; w + 7 <= w_hi; w += 8) {
+                    u32 x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) x[q] = *(const u32*)(img + (long long)(b + w + q) * a.image_bytes);
+                    for (int q = 0; q < 8; ++q) x[q] = *(const u32*)(img + (long long)(b + w + q) * a.image_bytes);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) sum += x[q];
-        }
-        for (; w <= w_hi; ++w) sum += *(const u32*)(img + (long long)(b + w) * a.image_bytes);
-        if (sum) {
-            const int bin = i / CB + 1, cl = i - (bin - 1) * CB;
-            if (kbase + cl < a.K) a.hist[(kbase + cl) * a.nbins + bin] += sum;
+                    for (int q = 0; q < 8; ++q) sum += x[q];
+                }
+                for (; w <= w_hi; ++w) sum += *(const u32*)(img + (long long)(b + w) * a.image_bytes);
+            }
+            tile[lb][lc] = sum;
+            __syncthreads();
+            const u64 v = tile[wb][wc];
+            if (v && wc < ct && bin0 + wb < a.BL && kbase + c0 + wc < a.K)
+                a.hist[(kbase + c0 + wc) * a.nbins + bin0 + wb + 1] += v;
+            __syncthreads();
         }
     }
     // the overflow tables of the bucket's runs: block y takes the runs w = w_lo + y, + gridDim.y, ...
@@ -1490,8 +1508,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     bk.images = ws + p.off_images;
     bk.image_bytes = p.image_bytes;
     hipLaunchKernelGGL(csr2_bucket_kernel, dim3(p.W), dim3(BBLOCK), (size_t)p.image_bytes + 8 * WTAB + HOT_LDS_BYTES, s, bk);
-    hipLaunchKernelGGL(csr2_reduce_kernel, dim3(p.NB, (p.CB * p.BL + BBLOCK - 1) / BBLOCK),
-                       dim3(BBLOCK), 0, s, bk);
+    hipLaunchKernelGGL(csr2_reduce_kernel, dim3(p.NB, (p.CB + RCT - 1) / RCT), dim3(BBLOCK), 0, s, bk);
     DME_HIP_CHECK(hipGetLastError());
     return DME_OK;
 }
