@@ -32,5 +32,6 @@ step weighted 200 python3 benchmarks/weighted_em.py > $OUT/weighted_em.json 2> $
 step weighted_pmc 300 bash benchmarks/pmc_weighted.sh $OUT/weighted_pmc_sq.txt
 step heavy_tail 300 python3 benchmarks/heavy_tail.py > $OUT/heavy_tail.json 2> $OUT/heavy_tail.err
 step roctx 300 bash -c "cd /tmp && rm -rf /tmp/mk && DME_ROCTX=1 rocprofv3 --kernel-trace --marker-trace -d /tmp/mk -o m -- python3 $ROOT/bench.py --no-cpu-baseline --steps 3 --warmup 1 --settle-seconds 0 > /tmp/mk.json 2>/tmp/mk.err; python3 $ROOT/benchmarks/roctx_ranges.py /tmp/mk/m_results.db > $OUT/roctx_ranges.txt 2>&1"
-step dense_shapes 900 python3 benchmarks/dense_shapes.py > $OUT/dense_shapes.txt 2> $OUT/dense_shapes.err
+# (SKIP_DENSE=1: without the 33-shape table, which takes ten minutes and only changes with dme_stats.hip)
+[ -n "$SKIP_DENSE" ] || step dense_shapes 900 python3 benchmarks/dense_shapes.py > $OUT/dense_shapes.txt 2> $OUT/dense_shapes.err
 echo done
