@@ -471,6 +471,9 @@ __device__ __forceinline__ PartV ld_part(const Partial* p) {
 // keep their order (same bits as one by one), but a long column - heavy-tailed counts: 38 slots at
 // 9700 bins - no longer pays a memory round trip per slot (BASELINE configs[4]: 0.45 -> 0.36 ms
 // for the 13-iteration solve).
+// DEEP: eight slots in flight for the long columns of heavy-tailed counts (the kernels without the
+// (Beta, W) terms that take their partial sums from the table; elsewhere the 40 registers it takes spill).
+template <bool DEEP>
 __device__ __forceinline__ void gather_slots(const Partial* base, long long from, long long cnt,
                                              const PartV* first, DmeAcc& a0, DmeAcc& a1, double& a2) {
     auto add = [&](const PartV& p) {
@@ -480,6 +483,15 @@ __device__ __forceinline__ void gather_slots(const Partial* base, long long from
     };
     if (first) add(*first);
     long long i = from;
+    if constexpr (DEEP) {
+        for (; i + 7 < cnt; i += 8) {  // (38 slots are five round trips instead of ten)
+            PartV p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = ld_part(base + i + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) add(p[u]);
+        }
+    }
     for (; i + 3 < cnt; i += 4) {
         const PartV p0 = ld_part(base + i), p1 = ld_part(base + i + 1), p2 = ld_part(base + i + 2),
                     p3 = ld_part(base + i + 3);
@@ -653,7 +665,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
                 const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
                 DmeAcc a0{0, 0}, a1{0, 0};
                 double a2 = 0.0;
-                if (cnt > 0) gather_slots(w.part + eval_slot_base(e, k, S), 1, cnt, &pf->p[c], a0, a1, a2);
+                if (cnt > 0) gather_slots<false>(w.part + eval_slot_base(e, k, S), 1, cnt, &pf->p[c], a0, a1, a2);
                 column(k, a0, a1, a2);
             }
         }
@@ -663,7 +675,7 @@ __device__ Gathered gather_eval(const Ws& w, const EvalArgs& e, long long K, dou
             const long long cnt = L > 0 ? (L + SEG - 1) / SEG : 0;
             DmeAcc a0{0, 0}, a1{0, 0};
             double a2 = 0.0;
-            gather_slots(w.part + eval_slot_base(e, k, S), 0, cnt, nullptr, a0, a1, a2);
+            gather_slots<!CPT>(w.part + eval_slot_base(e, k, S), 0, cnt, nullptr, a0, a1, a2);
             column(k, a0, a1, a2);
         }
     }

@@ -14,11 +14,20 @@ import numpy as np, torch
 from bayespy_amd import _lib
 _lib.LIB_PATH = os.path.abspath("bayespy_amd/libdme_ts.so")
 from bayespy_amd import device as dev
-K, N, M = 1000, 2_000_000, 500
-rng = np.random.default_rng(0)
-alpha = 0.01 + rng.gamma(2.0, 0.05, size=K)
-tot = torch.randint(1, M + 1, (N,), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
-X = dev.synth_dirmult(N, K, alpha, tot, seed=3)
+if os.environ.get("HEAVY"):  # BASELINE configs[4]: K = 100, heavy-tailed row totals (benchmarks/heavy_tail.py)
+    K, N = 100, 1_000_000
+    rng = np.random.default_rng(20260005)
+    alpha = 0.05 + rng.gamma(2.0, 0.3, size=K)
+    u = torch.rand(N, device="cuda", dtype=torch.float64, generator=torch.Generator(device="cuda").manual_seed(5))
+    tot = torch.clamp(torch.floor(5.0 * (1.0 - u) ** (-1.0 / 1.2)), max=100000).to(torch.int32)
+    X = dev.synth_dirmult(N, K, alpha, tot, seed=20260005, dtype=torch.int32)
+    M = int(tot.max())
+else:
+    K, N, M = 1000, 2_000_000, 500
+    rng = np.random.default_rng(0)
+    alpha = 0.01 + rng.gamma(2.0, 0.05, size=K)
+    tot = torch.randint(1, M + 1, (N,), dtype=torch.int32, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    X = dev.synth_dirmult(N, K, alpha, tot, seed=3)
 for rep in range(3):
     st = dev.DeviceStats(K, M, M)
     st.add_dense(X, max_count=M, max_total=M)
