@@ -119,12 +119,12 @@ inline bool plan(long long N, long long nnz, long long K, long long nbins, Plan*
     long long o = 0;
     p->off_head = o;     o = align256(o + 256);
     p->off_flag = o;     o = align256(o + 256);
+    p->off_bcount = o;   o = align256(o + 4 * MAXB);   // (flag, bcount and rstart lie side by side: one memset)
     p->off_rstart = o;   o = align256(o + 8 * (G3 + 1));
     p->off_cbucket = o;  o = align256(o + p->max_chunks);
     p->off_cfill = o;    o = align256(o + 2 * p->max_chunks);
     p->off_sorted = o;   o = align256(o + 4 * p->max_chunks);
     p->off_bstart = o;   o = align256(o + 4 * (MAXB + 2));
-    p->off_bcount = o;   o = align256(o + 4 * MAXB);
     p->off_bpos = o;     o = align256(o + 4 * MAXB);
     p->off_images = o;   o = align256(o + (long long)(p->NB + p->W) * p->image_bytes);
     p->off_chunks = o;   o = align256(o + p->max_chunks * CHUNK * 4LL + (long long)p->G3 * TILE * 4LL);  // + the tile kernel's dump areas
@@ -520,6 +520,7 @@ struct TileArgs {
     u32* flag;             // written by the check kernel: != 0 = malformed rowptr
     u64* ts;               // phase time stamps (-DDME_CSR3_TS builds)
     long long* rstart;     // [G + 1] number of rows that start before E0 + g S; [G]: before rowptr[N]
+    u32* bcount;           // [MAXB] chunks that hold records, per bucket (zeroed per call): what the chunk sort starts from
     int G;
     long long chunks_per_wg;
 };
@@ -579,6 +580,7 @@ struct TileLds {
     u32 staged;           // records of the tile in the staging area
     u32 len[MAXB];        // records written to the bucket's stream so far
     u32 cur[MAXB];        // id of the stream's last chunk
+    u32 nch[MAXB];        // chunks the stream has taken
     u32 wsum[8], wrows[8];   // per wave (T3W <= 8; the rest stays 0)
     u32 WR[T3W];          // window index + 1 of the row that holds the entry in front of wave w's first
     u32 straddle;         // window index + 1 of the row that runs over the tile's end
@@ -635,6 +637,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
         L.cnt[tid] = 0;
         L.len[tid] = 0;
         L.cur[tid] = 0xFFFFFFFFu;
+        L.nch[tid] = 0;
     }
     if (tid < 8) L.stat[tid] = 0;
     if (tid < T3W) L.WR[tid] = 0;
@@ -877,6 +880,7 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
                     if (id0 + nnew <= climit) {
                         d1 = ((u32)id0 << 10) - split;
                         lastid = (u32)(id0 + nnew - 1);
+                        L.nch[lane] += nnew;
                         for (u32 q = 0; q < nnew; ++q) {
                             a.chunk_bucket[id0 + q] = (unsigned char)lane;
                             a.chunk_fill[id0 + q] = (unsigned short)CHUNK;  // the stream's last one: corrected at the end
@@ -1028,6 +1032,9 @@ __global__ __launch_bounds__(T3, 4) void csr3_part_kernel(TileArgs ta) {
     if (tid < a.NB) {
         const u32 n = L.len[tid], id = L.cur[tid];
         if (n > 0 && (n & (CHUNK - 1)) && id != 0xFFFFFFFFu) a.chunk_fill[id] = (unsigned short)(n & (CHUNK - 1));
+        // the chunk sort's counts: every chunk taken holds records (768 workgroups x 49 adds at their own
+        // ends, instead of a counting pass over the whole chunk table behind this kernel: 22 us + a memset)
+        if (L.nch[tid]) atomicAdd(&ta.bcount[tid], L.nch[tid]);
     }
     const u32 mv = dme_wave_max_u32(maxv), mt = dme_wave_max_u32(maxt32);
     if (lane == 0) {
@@ -1055,7 +1062,11 @@ constexpr int SGRID = 1024;         // (128 workgroups measured the same: 20 + 2
 __global__ __launch_bounds__(SBLOCK) void csr2_sort_count_kernel(long long max_chunks,
                                                                  const unsigned char* chunk_bucket,
                                                                  const unsigned short* chunk_fill,
-                                                                 u32* bcount /*[MAXB], zeroed*/) {
+                                                                 u32* bcount /*[MAXB], zeroed*/,
+                                                                 const u32* rowptr_bad) {
+    // (the tile kernel has counted its chunks itself; this pass is for the row-wise kernel, which only
+    // runs when rowptr is malformed - uniform over the grid)
+    if (*rowptr_bad == 0) return;
     __shared__ u32 cnt[MAXB];
     const int tid = threadIdx.x;
     if (tid < MAXB) cnt[tid] = 0;
@@ -1463,6 +1474,7 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     DME_HIP_CHECK(hipMemsetAsync(ws + p.off_head, 0, 256, s));
 #endif
     ta.rstart = (long long*)(ws + p.off_rstart);
+    ta.bcount = (u32*)(ws + p.off_bcount);
     ta.G = p.G3;
     ta.chunks_per_wg = p.chunks_per_wg3;
     a.rowptr_bad = ta.flag;
@@ -1495,9 +1507,8 @@ int dme_csr2_run(const long long* rowptr, const int* colidx, const int* vals, lo
     u32* bstart = (u32*)(ws + p.off_bstart);
     u32* bcount = (u32*)(ws + p.off_bcount);
     u32* bpos = (u32*)(ws + p.off_bpos);
-    DME_HIP_CHECK(hipMemsetAsync(bcount, 0, 4 * MAXB, s));
     hipLaunchKernelGGL(csr2_sort_count_kernel, dim3(SGRID), dim3(SBLOCK), 0, s, p.max_chunks, (const unsigned char*)a.chunk_bucket,
-                       (const unsigned short*)a.chunk_fill, bcount);
+                       (const unsigned short*)a.chunk_fill, bcount, (const u32*)ta.flag);
     hipLaunchKernelGGL(csr2_sort_scan_kernel, dim3(1), dim3(64), 0, s, (const u32*)bcount, p.NB, bstart, bpos);
     hipLaunchKernelGGL(csr2_sort_fill_kernel, dim3(SGRID), dim3(SBLOCK), 0, s, p.max_chunks, (const unsigned char*)a.chunk_bucket,
                        (const unsigned short*)a.chunk_fill, bpos, sorted);
