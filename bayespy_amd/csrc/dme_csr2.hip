@@ -540,7 +540,17 @@ __global__ __launch_bounds__(256) void csr3_check_kernel(const long long* rowptr
             bad = true;
         } else if (p1 > p0 && p0 >= E0 && p1 <= E1) {
             // the boundaries E0 + g S in (p0, p1]: row j is the last one that starts before them
-            long long g_lo = (p0 - E0) / S + 1, g_hi = (p1 - E0) / S;
+            // (a 32-bit division whenever the span allows, a third of a 64-bit one's cost; the second one
+            // only for the few rows that do hold a boundary)
+            long long g_lo, g_hi;
+            if (span < (1LL << 32)) {
+                const u32 x0 = (u32)(p0 - E0), x1 = (u32)(p1 - E0), q1 = x1 / (u32)S;
+                g_hi = (long long)q1;
+                g_lo = (long long)((u64)x0 >= (u64)q1 * (u64)S ? q1 : x0 / (u32)S) + 1;
+            } else {
+                g_lo = (p0 - E0) / S + 1;
+                g_hi = (p1 - E0) / S;
+            }
             if (g_hi > G - 1) g_hi = G - 1;
             for (long long g = g_lo; g <= g_hi; ++g) rstart[g] = j + 1;
             if (p1 == E1) rstart[G] = j + 1;
