@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(SBLOCK) void csr2_sort_fill_kernel(long long max_ch
     const int tid = threadIdx.x;
     const long long nc = max_chunks;
     // a workgroup's chunks: the contiguous slice [lo, hi)
-    const long long per = (nc + SGRID - 1) / SGRID;
+    const long long per = (nc + (long long)gridDim.x - 1) / (long long)gridDim.x;
     const long long lo = (long long)blockIdx.x * per;
     long long hi = lo + per;
     if (hi > nc) hi = nc;
