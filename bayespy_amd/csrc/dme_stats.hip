@@ -1235,17 +1235,30 @@ __global__ __launch_bounds__(PAIR_BLOCK) void stats_pair_kernel(PairArgs a) {
     if (tid >= 4 && tid <= 5 && sh_stat[tid]) atomicMax(&a.status[tid], sh_stat[tid]);
 }
 
-// pairs[c] = sum over the images and their copies; block (64, RED_SLICES): a thread column per cell
+// pairs[c] = sum over the images and their copies; block (64, RED_SLICES): a thread column per cell.
+// The G * CP words of a cell are taken eight at a time (eight loads in flight: with one at a time a
+// small input - BASELINE configs[1], 122 images - spent 20 us here on memory latency alone).
 __global__ __launch_bounds__(64 * RED_SLICES) void pair_sum_kernel(PairArgs a) {
     __shared__ u64 sh[RED_SLICES][64];
     const long long ncell = (long long)a.B1 * a.B1;
     const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
     u64 s = 0;
-    if (c < ncell)
-        for (long long g = threadIdx.y; g < a.G; g += RED_SLICES) {
-            const u32* img = a.hist_part + g * a.part_words + c;
-            for (int cp = 0; cp < a.CP; ++cp) s += img[(long long)cp * a.cstride];
+    if (c < ncell) {
+        const long long total = a.G * a.CP;  // word j of the cell: image j / CP, copy j % CP (CP is a power of two)
+        const int cpm = a.CP - 1, cps = __ffs(a.CP) - 1;
+        auto word = [&](long long j) -> u32 {
+            return a.hist_part[(j >> cps) * a.part_words + (long long)(j & cpm) * a.cstride + c];
+        };
+        long long j = threadIdx.y;
+        for (; j + 7 * RED_SLICES < total; j += 8 * RED_SLICES) {
+            u32 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = word(j + u * RED_SLICES);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += x[u];
         }
+        for (; j < total; j += RED_SLICES) s += word(j);
+    }
     sh[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && c < ncell) {
@@ -1256,38 +1269,30 @@ __global__ __launch_bounds__(64 * RED_SLICES) void pair_sum_kernel(PairArgs a) {
     }
 }
 
-// one workgroup: the marginals of the pair counts
+// one workgroup: the marginals of the pair counts.  ONE pass over the cells: a cell (x0, x1) adds its rows
+// to three LDS tables - column 0's count x0, column 1's count x1, the row total x0 + x1 - and its share to
+// the mean accumulators (per thread in cell order, then a tree: as before, the same bits); the tables
+// then go to hist / histV.  (Three passes before, a thread walking a whole row or column of the pair
+// table by itself: 23 us for 61 x 61 cells.)
 __global__ __launch_bounds__(1024) void pair_marginals_kernel(PairArgs a) {
     __shared__ double sh0[1024], sh1[1024];
+    __shared__ u64 h0[1024], h1[1024], ht[2048];  // B1 <= 1024 (stats_pair_run)
     __shared__ u64 sh_max[2];
     const int tid = threadIdx.x, B1 = a.B1;
     if (tid < 2) sh_max[tid] = 0;
+    h0[tid] = 0;
+    h1[tid] = 0;
+    ht[tid] = 0;
+    ht[tid + 1024] = 0;
     __syncthreads();
-    for (int v = 1 + tid; v < B1; v += 1024) {
-        u64 h0 = 0, h1 = 0;
-        for (int o = 0; o < B1; ++o) {
-            h0 += a.pairs[(long long)v * B1 + o];
-            h1 += a.pairs[(long long)o * B1 + v];
-        }
-        if (h0) a.hist[v] += h0;
-        if (h1) a.hist[a.nbins + v] += h1;
-        if (h0 | h1) atomicMax(&sh_max[0], (u64)v);
-    }
-    for (int t = 1 + tid; t <= 2 * (B1 - 1); t += 1024) {
-        u64 cnt = 0;
-        const int lo = t - (B1 - 1) > 0 ? t - (B1 - 1) : 0, hi = t < B1 - 1 ? t : B1 - 1;
-        for (int x0 = lo; x0 <= hi; ++x0) cnt += a.pairs[(long long)x0 * B1 + (t - x0)];
-        if (cnt) {
-            atomicMax(&sh_max[1], (u64)t);
-            if ((long long)t < a.tbins) a.histV[t] += cnt;
-            else atomicAdd(&a.status[2], cnt);
-        }
-    }
     double s0 = 0.0, s1 = 0.0;
     for (int c = tid; c < B1 * B1; c += 1024) {
         const u64 n = a.pairs[c];
         if (n) {
             const int x0 = c / B1, x1 = c - x0 * B1;
+            atomicAdd(&h0[x0], n);
+            atomicAdd(&h1[x1], n);
+            atomicAdd(&ht[x0 + x1], n);
             const double w = __ddiv_rn(1.0, __dadd_rn(1.0, (double)(x0 + x1)));
             s0 = __dadd_rn(s0, __dmul_rn(__dmul_rn((double)n, (double)x0), w));
             s1 = __dadd_rn(s1, __dmul_rn(__dmul_rn((double)n, (double)x1), w));
@@ -1296,6 +1301,20 @@ __global__ __launch_bounds__(1024) void pair_marginals_kernel(PairArgs a) {
     sh0[tid] = s0;
     sh1[tid] = s1;
     __syncthreads();
+    for (int v = 1 + tid; v < B1; v += 1024) {
+        const u64 c0 = h0[v], c1 = h1[v];
+        if (c0) a.hist[v] += c0;
+        if (c1) a.hist[a.nbins + v] += c1;
+        if (c0 | c1) atomicMax(&sh_max[0], (u64)v);
+    }
+    for (int t = 1 + tid; t <= 2 * (B1 - 1); t += 1024) {
+        const u64 cnt = ht[t];
+        if (cnt) {
+            atomicMax(&sh_max[1], (u64)t);
+            if ((long long)t < a.tbins) a.histV[t] += cnt;
+            else atomicAdd(&a.status[2], cnt);
+        }
+    }
     for (int d = 512; d > 0; d >>= 1) {
         if (tid < d) {
             sh0[tid] = __dadd_rn(sh0[tid], sh0[tid + d]);

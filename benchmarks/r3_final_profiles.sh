@@ -25,6 +25,7 @@ for rows in 5000000 2500000 1250000; do
   step share_$rows 200 python3 bench.py --rows $rows --force-collective --no-cpu-baseline > $OUT/share_rows_$rows.json 2> $OUT/share_rows_$rows.err
 done
 step share_10000000 200 python3 bench.py --force-collective --no-cpu-baseline > $OUT/share_rows_10000000.json 2> $OUT/share_rows_10000000.err
+step c2 200 python3 bench.py --k 2 --rows 1000000 --max-total 60 --dtype i32 --no-cpu-baseline > $OUT/bench_c2_k2_1M.json 2> $OUT/bench_c2_k2_1M.err
 step csr 400 bash benchmarks/ab_csr.sh 12500000 $OUT/csr_bow12p5M_kernel_stats.txt bayespy_amd/libdme_hip.so
 step csr_steps 300 python3 benchmarks/bow_csr.py --rows 12500000 --steps 16 --warmup 2 --solve > $OUT/csr_bow12p5M.json 2> $OUT/csr_bow12p5M.err
 step csr_traffic 500 bash benchmarks/pmc_csr_traffic.sh 12500000 $OUT/csr_pmc_traffic.txt
