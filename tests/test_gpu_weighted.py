@@ -132,3 +132,45 @@ def test_weighted_images_path_vs_oracle_and_atomics_path(oracle, N, K, C, vmax, 
         assert torch.equal(uvs[c].Uf, one.Uf) and torch.equal(uvs[c].Vf, one.Vf)
         assert torch.equal(uvs[c].lenU, one.lenU) and torch.equal(uvs[c].lenV, one.lenV)
     # bit-reproducible for the same images? no: LDS atomics inside a workgroup add in arrival order.
+
+
+def test_weighted_workspace_entry_edge_cases(oracle):
+    """dme_stats_dense_weighted_batch_ws_i32 through the raw C ABI: a workspace that is too small (the pass
+    of the entry without one, same statistics), a misaligned one (refused), no rows (nothing happens), and
+    the workspace query for shapes it does not take (0)."""
+    from bayespy_amd import device, _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    N, K, C = 12_000, 50, 3
+    X = _rows(rng, N, K, 9, 0.5)
+    R = rng.dirichlet(np.ones(C), size=N)
+    mc, mt = int(X.max()), int(X.sum(axis=1).max())
+    Xd, Rd = torch.from_numpy(X).cuda(), torch.from_numpy(R).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(ws_ptr, ws_bytes, n=N):
+        st = device.WeightedStats(K, C=C)
+        st.reserve(mc, mt)
+        rc = L.dme_stats_dense_weighted_batch_ws_i32(
+            Xd.data_ptr(), Rd.data_ptr(), C, n, K, Xd.stride(0), st.histW.data_ptr(), st.nbins,
+            st.histVW.data_ptr(), st.tbins, st.maxcol.data_ptr(), st.maxtot.data_ptr(), st.status.data_ptr(),
+            ws_ptr, ws_bytes, stream)
+        torch.cuda.synchronize()
+        return rc, st
+
+    need = int(L.dme_stats_weighted_workspace_bytes(K, C, mc + 1, mt + 1))
+    assert need > 0 and L.dme_stats_weighted_workspace_bytes(K, 65, 4, 4) == 0
+    ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+    rc_full, full = run(ws.data_ptr(), need)
+    rc_small, small = run(ws.data_ptr(), 4096)          # too small: atomics, not an error
+    rc_none, none = run(None, 0)
+    assert rc_full == 0 and rc_small == 0 and rc_none == 0
+    for other in (small, none):
+        np.testing.assert_allclose(full.histW.cpu().numpy(), other.histW.cpu().numpy(), rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(full.histVW.cpu().numpy(), other.histVW.cpu().numpy(), rtol=1e-12, atol=1e-300)
+    for c in range(C):
+        _compare(full.to_uv(c), oracle.append_rows_weighted(X, R[:, c]))
+    rc_bad, _ = run(ws.data_ptr() + 4, need)            # 4-byte aligned only
+    assert rc_bad != 0 and b"aligned" in L.dme_last_error()
+    rc_empty, empty = run(ws.data_ptr(), need, n=0)
+    assert rc_empty == 0 and float(empty.histW.abs().sum()) == 0.0 and int(empty.status[0]) == 0
