@@ -174,3 +174,37 @@ def test_weighted_workspace_entry_edge_cases(oracle):
     assert rc_bad != 0 and b"aligned" in L.dme_last_error()
     rc_empty, empty = run(ws.data_ptr(), need, n=0)
     assert rc_empty == 0 and float(empty.histW.abs().sum()) == 0.0 and int(empty.status[0]) == 0
+
+
+def test_weighted_images_path_at_full_grid_against_torch_reductions():
+    """300 000 rows (one workgroup per CU, the bench's grid) of K = 100 with five weights per row: every
+    (component, column, count) cell and every (component, row total) cell against fp64 index_add_
+    reductions by torch on the device, to 1e-11 (sums of the same weights in another order)."""
+    from bayespy_amd import device
+    N, K, C, M = 300_000, 100, 5, 100
+    rng = np.random.default_rng(3)
+    alpha = 0.05 + rng.gamma(2.0, 0.3, size=K)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    totals = torch.randint(1, M + 1, (N,), dtype=torch.int32, device="cuda", generator=g)
+    X = device.synth_dirmult(N, K, alpha, totals, seed=9, dtype=torch.int32, device=torch.device("cuda", 0))
+    R = torch.rand((N, C), dtype=torch.float64, device="cuda", generator=g)
+    R /= R.sum(dim=1, keepdim=True)
+    ws = device.WeightedStats(K, C=C)
+    ws.add_dense(X, R, M, M)
+    ws.check()
+    nb, tb = ws.nbins, ws.tbins
+    Xl = X.long()
+    cell = (torch.arange(K, device="cuda") * nb)[None, :] + Xl           # [N, K] index of (column, count)
+    tot = Xl.sum(dim=1)
+    got_h = ws.histW.view(C, K, nb)
+    got_v = ws.histVW.view(C, tb)
+    for c in range(C):
+        ref = torch.zeros(K * nb, dtype=torch.float64, device="cuda")
+        ref.index_add_(0, cell.reshape(-1), R[:, c:c + 1].expand(N, K).reshape(-1))
+        ref = ref.view(K, nb)
+        torch.testing.assert_close(got_h[c][:, 1:], ref[:, 1:], rtol=1e-11, atol=1e-13)
+        refv = torch.zeros(tb, dtype=torch.float64, device="cuda")
+        refv.index_add_(0, tot, R[:, c])
+        torch.testing.assert_close(got_v[c][1:], refv[1:], rtol=1e-11, atol=1e-13)
+    assert int(ws.status[0]) == N and int(ws.maxtot[0]) == int(tot.max())
+    assert torch.equal(ws.maxcol, Xl.max(dim=0).values)
