@@ -835,7 +835,8 @@ def _narrow_case(oracle, K, N, big, cus, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["u16", "i32", "i32-negatives"])
-@pytest.mark.parametrize("max_count,max_total", [(40, 80), (20, 30), (33, 35)])
+# (the last two: 81 and 151 bins a side - four copies of the pair table in LDS, and one)
+@pytest.mark.parametrize("max_count,max_total", [(40, 80), (20, 30), (33, 35), (80, 120), (150, 200)])
 def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, max_total, dtype):
     """K = 2 in uint16 rows that lie back to back counts the pairs (x0, x1) in LDS and derives
     hist / histV / the mean accumulator from them (stats_pair_kernel); the same rows at a pitch of 4
@@ -851,6 +852,8 @@ def test_pair_counts_of_two_columns_equal_the_general_kernel(oracle, max_count, 
     X[::5] = (0, 33)
     X[1::7] = 0
     X[2::11] = (17, 0)
+    if max_count >= 80:                                   # counts over the whole table
+        X[3::19] = rng.integers(0, max_count // 2, size=X[3::19].shape)
     negatives = dtype == "i32-negatives"
     if negatives:
         X[3::13, 0] = -5
